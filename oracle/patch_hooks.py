@@ -1,0 +1,100 @@
+"""Restatement of the reference's joint-attention block hooks.  ORACLE - test infrastructure only.
+
+Follows /root/reference/patch/patch.py: ``initialize_joint_layers`` :143-172 (attn1n = deepcopy(attn1), zero-init
+``conv1n``), ``ToMeBlock.forward`` joint branch :438-501, ``forward_temporal`` joint branch :616-658, partner selection
+by boolean-mask swap :466-468, optional frame flip :471-475, ``post`` variants :484-494.
+
+Pinned: tests/golden/patch_joint.safetensors holds outputs of the reference's own ToMeBlock code (run through
+name-only stubs by tests/golden/make_goldens.py) on the blocks of oracle/blocks.py.
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+import torch.nn as nn
+
+from .blocks import BasicTransformerBlock, TemporalBasicTransformerBlock
+
+
+def initialize_joint_layers(block: nn.Module, post: str = "conv") -> None:
+    block.attn1n = copy.deepcopy(block.attn1)
+    dim = block.attn1n.out_dim
+    if post == "conv":
+        block.conv1n = nn.Linear(dim, dim, bias=False)
+        nn.init.zeros_(block.conv1n.weight)
+    elif post == "scale":
+        block.scale1n = nn.Parameter(torch.zeros(1, 1, dim))
+    elif post == "conv_fuse":
+        block.conv1n = nn.Linear(dim * 2, dim * 2, bias=False)
+        nn.init.zeros_(block.conv1n.weight)
+    else:
+        raise AssertionError(post)
+    block.post = post
+    block.joint_scale = 1.0
+
+
+def _partner(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """joint_encoder_hidden_states[~m] = x[m]; [m] = x[~m]  (patch.py:466-468)."""
+    mask = mask.repeat_interleave(x.shape[0] // len(mask), dim=0)
+    out = torch.empty_like(x)
+    out[~mask] = x[mask]
+    out[mask] = x[~mask]
+    return out, mask
+
+
+def _post(block, o1n, mask):
+    if block.post == "conv":
+        return block.conv1n(o1n)
+    if block.post == "scale":
+        return block.scale1n * o1n
+    cat = torch.cat([o1n[mask], o1n[~mask]], dim=-1)
+    fx, fy = block.conv1n(cat).chunk(2, dim=-1)
+    o1n = o1n.clone()
+    o1n[mask] = fx
+    o1n[~mask] = fy
+    return o1n
+
+
+def basic_block_forward(block: BasicTransformerBlock, hidden_states, encoder_hidden_states, joint_mask,
+                        enable_joint=True, flip=False, n_frames=None):
+    """patch.py:390-580 for norm_type == "layer_norm"."""
+    n = block.norm1(hidden_states)
+    attn_output = block.attn1(n)
+    if enable_joint:
+        partner, mask = _partner(n, joint_mask)
+        if flip:
+            bt, s, c = partner.shape
+            partner = partner.reshape(bt // n_frames, n_frames, s, c).flip(dims=[1]).reshape(bt, s, c)
+        o1n = block.attn1n(n, encoder_hidden_states=partner)
+        attn_output = attn_output + _post(block, o1n, mask) * block.joint_scale
+    hidden_states = attn_output + hidden_states
+    hidden_states = block.attn2(block.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states) + hidden_states
+    return block.ff(block.norm3(hidden_states)) + hidden_states
+
+
+def temporal_block_forward(block: TemporalBasicTransformerBlock, hidden_states, num_frames, encoder_hidden_states,
+                           joint_mask, enable_joint=True):
+    """patch.py:582-686."""
+    bf, s, c = hidden_states.shape
+    b = bf // num_frames
+    h = hidden_states[None, :].reshape(b, num_frames, s, c).permute(0, 2, 1, 3).reshape(b * s, num_frames, c)
+    residual = h
+    h = block.ff_in(block.norm_in(h))
+    if block.is_res:
+        h = h + residual
+    n = block.norm1(h)
+    attn_output = block.attn1(n)
+    if enable_joint:
+        partner, mask = _partner(n, joint_mask)
+        o1n = block.attn1n(n, encoder_hidden_states=partner)
+        if block.post == "conv":
+            o1n = block.conv1n(o1n)
+        elif block.post == "scale":
+            o1n = block.scale1n * o1n
+        attn_output = attn_output + o1n
+    h = attn_output + h
+    h = block.attn2(block.norm2(h), encoder_hidden_states=encoder_hidden_states) + h
+    ff = block.ff(block.norm3(h))
+    h = ff + h if block.is_res else ff
+    return h[None, :].reshape(b, s, num_frames, c).permute(0, 2, 1, 3).reshape(b * num_frames, s, c)

@@ -1,0 +1,458 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by EXECUTING THE REFERENCE'S OWN CODE.
+
+Runs only in the build container (needs /root/reference, read-only; never on the GPU box).  The reference's hot-path
+files import `diffusers`, `peft` and `core_qnn`, none of which is installed or installable here, so this script
+registers NAME-ONLY stubs for those packages in ``sys.modules`` (config plumbing, base classes, logging) and binds the
+block classes the reference asks diffusers for to the restatements in ``oracle/blocks.py``.  What the fixtures pin is
+therefore everything the reference itself implements on the path:
+
+* scheduler_kat.json      <- utils/scheduling_euler_discrete_karras_fix.py (whole file, unmodified)
+* unet_wiring.safetensors <- models/unet_spatio_temporal_condition_controlnet.py ``forward`` (stock signature, with
+                             and without ControlNet residuals) and models/unet_spatio_temporal_condition.py
+                             ``forward`` (LK signature incl. the latent-knowledge fuse), tiny config
+* patch_joint.safetensors <- patch/patch.py ``apply_patch`` + ``ToMeBlock.forward`` / ``forward_temporal`` joint branch
+* loop.safetensors        <- pipeline/pipeline_stable_video_diffusion_trans.py ``__call__`` (output_type="latent")
+                             with stand-in CLIP/VAE stages (boundary stages, outside the hot path)
+
+Weights are NOT stored: they are regenerated from ``oracle.unet.init_weights_(seed)`` (a checksum is stored).
+No reference source text is copied into the repo; fixtures are tensors and scalars only.
+
+Usage:  python tests/golden/make_goldens.py
+"""
+from __future__ import annotations
+
+import enum
+import functools
+import importlib.util
+import inspect
+import json
+import logging as _pylogging
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+sys.dont_write_bytecode = True   # /root/reference is read-only: never drop __pycache__ there
+
+import numpy as np
+import torch
+import torch.nn as nn
+from safetensors.torch import save_file
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from oracle import blocks as ob            # noqa: E402
+from oracle import unet as ou              # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------ name-only stubs
+def _mod(name):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    parent, _, child = name.rpartition(".")
+    if parent:
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+class _FrozenDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class ConfigMixin:
+    """diffusers ConfigMixin, reduced to: ``register_to_config`` storage + attribute fallback to the config."""
+    config_name = None
+
+    def register_to_config(self, **kw):
+        object.__setattr__(self, "_internal_dict", _FrozenDict(kw))
+
+    @property
+    def config(self):
+        return self._internal_dict
+
+    def __getattr__(self, name):
+        d = self.__dict__.get("_internal_dict")
+        if d is not None and name in d:
+            return d[name]
+        sup = super()
+        if hasattr(sup, "__getattr__"):
+            return sup.__getattr__(name)      # nn.Module parameter/buffer/submodule lookup
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+
+def register_to_config(init):
+    @functools.wraps(init)
+    def inner(self, *args, **kwargs):
+        params = {n: p.default for i, (n, p) in enumerate(inspect.signature(init).parameters.items()) if i > 0}
+        new = {}
+        for a, n in zip(args, params.keys()):
+            new[n] = a
+        new.update({k: kwargs.get(k, d) for k, d in params.items() if k not in new})
+        self.register_to_config(**new)
+        init(self, *args, **kwargs)
+    return inner
+
+
+class BaseOutput:
+    pass
+
+
+class _Logging:
+    @staticmethod
+    def get_logger(name):
+        return _pylogging.getLogger(name)
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+    return torch.randn(tuple(shape), generator=generator, device=device, dtype=dtype)
+
+
+def install_stubs():
+    d = _mod("diffusers")
+    cu = _mod("diffusers.configuration_utils")
+    cu.ConfigMixin, cu.register_to_config = ConfigMixin, register_to_config
+    ut = _mod("diffusers.utils")
+    ut.BaseOutput, ut.logging = BaseOutput, _Logging
+    ut.replace_example_docstring = lambda s: (lambda f: f)
+    tu = _mod("diffusers.utils.torch_utils")
+    tu.randn_tensor = randn_tensor
+    tu.is_compiled_module = lambda m: False
+    _mod("diffusers.schedulers")
+    su = _mod("diffusers.schedulers.scheduling_utils")
+    su.KarrasDiffusionSchedulers = enum.Enum("KarrasDiffusionSchedulers", "EulerDiscreteScheduler DDIMScheduler")
+    su.SchedulerMixin = type("SchedulerMixin", (), {})
+    ld = _mod("diffusers.loaders")
+    for n in ("UNet2DConditionLoadersMixin", "PeftAdapterMixin", "FromSingleFileMixin"):
+        setattr(ld, n, type(n, (), {}))
+    dm = _mod("diffusers.models")
+    dm.AutoencoderKLTemporalDecoder = type("AutoencoderKLTemporalDecoder", (), {})
+    dm.UNetSpatioTemporalConditionModel = type("UNetSpatioTemporalConditionModel", (), {})
+    ap = _mod("diffusers.models.attention_processor")
+    ap.CROSS_ATTENTION_PROCESSORS = ()
+    ap.AttentionProcessor = type("AttentionProcessor", (), {})
+    ap.AttnProcessor = type("AttnProcessor", (), {})
+    ap.Attention = ob.Attention
+    em = _mod("diffusers.models.embeddings")
+    em.TimestepEmbedding, em.Timesteps = ob.TimestepEmbedding, ob.Timesteps
+    mu = _mod("diffusers.models.modeling_utils")
+    mu.ModelMixin = type("ModelMixin", (nn.Module,), {})
+    _mod("diffusers.models.unets")
+    b3 = _mod("diffusers.models.unets.unet_3d_blocks")
+    b3.UNetMidBlockSpatioTemporal = ob.UNetMidBlockSpatioTemporal
+    b3.get_down_block, b3.get_up_block = ob.get_down_block, ob.get_up_block
+    nm = _mod("diffusers.models.normalization")
+    for n in ("AdaLayerNorm", "AdaLayerNormContinuous", "AdaLayerNormZero", "RMSNorm"):
+        setattr(nm, n, type(n, (nn.Module,), {}))
+    ip = _mod("diffusers.image_processor")
+
+    class VaeImageProcessor:        # stand-in for a BOUNDARY stage (outside the hot path)
+        def __init__(self, vae_scale_factor=8):
+            self.vae_scale_factor = vae_scale_factor
+
+        def preprocess(self, image, height=None, width=None):
+            return 2.0 * image - 1.0
+    ip.VaeImageProcessor, ip.PipelineImageInput = VaeImageProcessor, object
+    _mod("diffusers.pipelines")
+    pu = _mod("diffusers.pipelines.pipeline_utils")
+
+    class DiffusionPipeline:
+        def register_modules(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        @property
+        def _execution_device(self):
+            return torch.device("cpu")
+
+        def progress_bar(self, total=None):
+            class _PB:
+                def __enter__(s): return s
+                def __exit__(s, *a): return False
+                def update(s): pass
+            return _PB()
+
+        def maybe_free_model_hooks(self):
+            pass
+    pu.DiffusionPipeline = DiffusionPipeline
+
+    _mod("peft"); _mod("peft.tuners"); _mod("peft.tuners.lora")
+    pl = _mod("peft.tuners.lora.layer")
+    pl.Linear = type("Linear", (nn.Module,), {})
+    pl.BaseTunerLayer = type("BaseTunerLayer", (), {})
+    _mod("core_qnn")
+    q = _mod("core_qnn.quaternion_layers")
+    q.QuaternionLinearAutograd = ob.QuaternionLinearAutograd
+    q.__all__ = ["QuaternionLinearAutograd"]
+
+
+def load_ref(relpath, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def checksum(model) -> float:
+    return float(sum(p.double().abs().sum() for p in model.parameters()))
+
+
+# ------------------------------------------------------------------------------------------------ 1. scheduler
+def gen_scheduler(sched_mod):
+    from oracle.scheduler import SchedulerConfig
+    cfg = SchedulerConfig().__dict__
+    out = {"config": cfg, "cases": []}
+    for n in (2, 3, 25):
+        s = sched_mod.EulerDiscreteScheduler(**cfg)
+        s.set_timesteps(n)
+        g = torch.Generator().manual_seed(100 + n)
+        x = torch.randn(1, 2, 4, 3, 3, generator=g) * float(s.init_noise_sigma)
+        case = {"n": n, "sigmas": s.sigmas.tolist(), "timesteps": s.timesteps.tolist(),
+                "init_noise_sigma": float(s.init_noise_sigma), "seed": 100 + n,
+                "x0": x.flatten().tolist(), "steps": []}
+        for t in s.timesteps:
+            v = torch.randn(x.shape, generator=g)
+            scaled = s.scale_model_input(x, t)
+            x = s.step(v, t, x).prev_sample
+            case["steps"].append({"v": v.flatten().tolist(), "scaled": scaled.flatten().tolist(),
+                                  "prev": x.flatten().tolist()})
+        out["cases"].append(case)
+    # the scalar KAT quoted in SURVEY.md 8c: x=1, v=0.5, first of 25 steps
+    s = sched_mod.EulerDiscreteScheduler(**cfg)
+    s.set_timesteps(25)
+    x = torch.ones(1)
+    out["scalar_kat"] = {"scaled": float(s.scale_model_input(x, s.timesteps[0])),
+                         "prev": float(s.step(torch.full((1,), 0.5), s.timesteps[0], x).prev_sample)}
+    with open(os.path.join(HERE, "scheduler_kat.json"), "w") as f:
+        json.dump(out, f)
+    print("scheduler: sigmas[25] head", out["cases"][2]["sigmas"][:3], "scalar", out["scalar_kat"])
+
+
+# ------------------------------------------------------------------------------------------------ 2. UNet wiring
+TINY = ou.TINY_CONFIG
+WSEED = 7
+
+
+def tiny_inputs(seed=11, frames=4, hw=8):
+    g = torch.Generator().manual_seed(seed)
+    return dict(
+        sample=torch.randn(2, frames, 8, hw, hw, generator=g),
+        enc=torch.randn(2, 1, 1024, generator=g),
+        ids=torch.tensor([[6.0, 127.0, 0.02]] * 2),
+        t=torch.tensor(1.6378),
+        domain=torch.randn(1, 1, 1000, generator=g),
+        flow=torch.randn(1, 1, 1000, generator=g),
+    )
+
+
+def skip_shapes(cfg, frames, hw):
+    boc = cfg.block_out_channels
+    n = 2 * frames
+    shapes = [(n, boc[0], hw, hw)]
+    r = hw
+    for i, c in enumerate(boc):
+        shapes += [(n, c, r, r)] * cfg.layers_per_block
+        if i != len(boc) - 1:
+            r //= 2
+            shapes.append((n, c, r, r))
+    return shapes, (n, boc[-1], r, r)
+
+
+def gen_unet(ref_stock, ref_lk):
+    kw = {k: v for k, v in TINY.__dict__.items()}
+    out = {}
+    inp = tiny_inputs()
+    with torch.no_grad():
+        m = ref_stock.UNetSpatioTemporalConditionControlNetModel(**kw)
+        ou.init_weights_(m, WSEED)
+        o = ou.UNetSpatioTemporalConditionControlNetModel(TINY)
+        o.load_state_dict(m.state_dict())          # name-for-name identical parameter tree
+        out["stock_checksum"] = torch.tensor(checksum(m), dtype=torch.float64)
+        out["stock_out"] = m(inp["sample"], inp["t"], inp["enc"], added_time_ids=inp["ids"], return_dict=False)[0]
+        # with ControlNet residuals (repeated-add quirk, App. C1)
+        g = torch.Generator().manual_seed(12)
+        shapes, mid_shape = skip_shapes(TINY, 4, 8)
+        down = tuple(0.1 * torch.randn(s, generator=g) for s in shapes)
+        mid = 0.1 * torch.randn(mid_shape, generator=g)
+        out["stock_out_ctrl"] = m(inp["sample"], inp["t"], inp["enc"], down_block_additional_residuals=down,
+                                  mid_block_additional_residual=mid, added_time_ids=inp["ids"],
+                                  return_dict=False)[0]
+        # python-float / int timesteps take the promotion branch (:390-404)
+        out["stock_out_tfloat"] = m(inp["sample"], 0.5, inp["enc"], added_time_ids=inp["ids"], return_dict=False)[0]
+
+        lk = ref_lk.UNetSpatioTemporalConditionModel(**kw)
+        ou.init_weights_(lk, WSEED + 1)
+        out["lk_checksum"] = torch.tensor(checksum(lk), dtype=torch.float64)
+        out["lk_out"] = lk(inp["sample"], inp["t"], inp["enc"], inp["domain"], inp["flow"],
+                           added_time_ids=inp["ids"], return_dict=False)[0]
+        # the fused embedding itself: capture what the first down block receives
+        cap = {}
+        def _cap(mod, a, k):
+            cap.setdefault("enc", k["encoder_hidden_states"])
+            return None
+        h = lk.down_blocks[0].register_forward_pre_hook(_cap, with_kwargs=True)
+        lk(inp["sample"], inp["t"], inp["enc"], inp["domain"], inp["flow"], added_time_ids=inp["ids"])
+        h.remove()
+        out["lk_fused_enc"] = cap["enc"][::4].contiguous()   # repeat_interleave(4) undone -> [2,1,1024]
+    for k, v in inp.items():
+        out["in_" + k] = v
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_wiring.safetensors"))
+    print("unet wiring: stock std %.4f ctrl std %.4f lk std %.4f" % (
+        out["stock_out"].std(), out["stock_out_ctrl"].std(), out["lk_out"].std()))
+
+
+# ------------------------------------------------------------------------------------------------ 3. patch hooks
+class _Holder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.spatial = ob.BasicTransformerBlock(128, 2, 64, 1024)
+        self.temporal = ob.TemporalBasicTransformerBlock(128, 128, 2, 64, 1024)
+
+    def forward(self, x):
+        return x
+
+
+def gen_patch(patch_mod):
+    torch.manual_seed(21)
+    holder = _Holder()
+    ou.init_weights_(holder, 21)
+    # `apply_patch` wants a ModelMixin-named class in the MRO
+    holder.__class__ = type("Holder", (_Holder, sys.modules["diffusers.models.modeling_utils"].ModelMixin), {})
+    out = {}
+    frames, S, C = 3, 16, 128
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(4 * frames, S, C, generator=g)          # batch [start,end] x CFG, masks [0,1,0,1]
+    enc = torch.randn(4 * frames, 1, 1024, generator=g)
+    tctx = torch.randn(4 * S, 1, 1024, generator=g)
+    mask = [False, True, False, True]
+    with torch.no_grad():
+        for flip in (False, True):
+            patch_mod.apply_patch(holder, flip=flip, with_spatial_block=True, with_temporal_block=True)
+            patch_mod.initialize_joint_layers(holder, post="conv")
+            patch_mod.set_joint_attention_mask(holder, mask)
+            # zero-init conv1n => identity; give it weights so the joint branch is exercised
+            gg = torch.Generator().manual_seed(23)
+            for blk in (holder.spatial, holder.temporal):
+                blk.conv1n.weight.copy_(torch.randn(C, C, generator=gg) / C ** 0.5)
+                for p in blk.attn1n.parameters():
+                    p.add_(0.05 * torch.randn(p.shape, generator=gg))
+            holder._tome_info["size"] = (4, frames, C, 4, 4)
+            tag = "flip" if flip else "noflip"
+            patch_mod.set_joint_attention(holder, True)
+            out[f"spatial_joint_{tag}"] = holder.spatial(x, encoder_hidden_states=enc)
+            if not flip:
+                out["temporal_joint"] = holder.temporal(x, num_frames=frames, encoder_hidden_states=tctx)
+                patch_mod.set_joint_scale(holder, 0.5)
+                out["spatial_joint_scale05"] = holder.spatial(x, encoder_hidden_states=enc)
+                patch_mod.set_joint_scale(holder, 1.0)
+                patch_mod.set_joint_attention(holder, False)
+                out["spatial_nojoint"] = holder.spatial(x, encoder_hidden_states=enc)
+                out["temporal_nojoint"] = holder.temporal(x, num_frames=frames, encoder_hidden_states=tctx)
+                out["conv1n_spatial"] = holder.spatial.conv1n.weight.clone()
+                out["conv1n_temporal"] = holder.temporal.conv1n.weight.clone()
+                for n, p in holder.spatial.attn1n.named_parameters():
+                    out["attn1n_spatial." + n] = p.clone()
+                for n, p in holder.temporal.attn1n.named_parameters():
+                    out["attn1n_temporal." + n] = p.clone()
+            patch_mod.remove_patch(holder)
+    out["in_x"], out["in_enc"], out["in_tctx"] = x, enc, tctx
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "patch_joint.safetensors"))
+    print("patch: joint vs nojoint delta %.4f" % (out["spatial_joint_noflip"] - out["spatial_nojoint"]).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ 4. pipeline loop
+class _FakeVAE(nn.Module):
+    """Boundary stand-in: 8x average pool + fixed channel mix -> 4 latent channels."""
+    def __init__(self):
+        super().__init__()
+        self.config = SimpleNamespace(block_out_channels=(1, 1, 1, 1), force_upcast=False, scaling_factor=0.18215)
+        g = torch.Generator().manual_seed(31)
+        self.mix = nn.Parameter(torch.randn(4, 3, generator=g))
+
+    @property
+    def dtype(self):
+        return self.mix.dtype
+
+    def encode(self, image):
+        z = torch.nn.functional.avg_pool2d(image, 8)
+        z = torch.einsum("oc,bchw->bohw", self.mix, z) * 0.18215
+        return SimpleNamespace(latent_dist=SimpleNamespace(mode=lambda: z))
+
+
+class _FakeCLIP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(32)
+        self.w = nn.Parameter(torch.randn(1024, 3, generator=g))
+
+    def forward(self, image):
+        return SimpleNamespace(image_embeds=torch.einsum("oc,bc->bo", self.w, image.mean(dim=(2, 3))))
+
+
+def gen_loop(pipe_mod, ref_stock, sched_mod):
+    from oracle.scheduler import SchedulerConfig
+    kw = {k: v for k, v in TINY.__dict__.items()}
+    unet = ref_stock.UNetSpatioTemporalConditionControlNetModel(**kw)
+    ou.init_weights_(unet, WSEED)
+    sched = sched_mod.EulerDiscreteScheduler(**SchedulerConfig().__dict__)
+    fe = lambda images, **k: SimpleNamespace(pixel_values=images)   # noqa: E731
+    pipe = pipe_mod.StableVideoDiffusionPipeline(vae=_FakeVAE(), image_encoder=_FakeCLIP(), unet=unet,
+                                                 scheduler=sched, feature_extractor=fe)
+    g = torch.Generator().manual_seed(41)
+    image = torch.rand(1, 3, 64, 64, generator=g)
+    lat0 = torch.randn(1, 4, 4, 8, 8, generator=g)
+    rec = {}
+    orig_forward = unet.forward
+
+    def spy(sample, t, **k):
+        y = orig_forward(sample, t, **k)
+        if "in0" not in rec:
+            rec["in0"], rec["out0"] = sample.clone(), y[0].clone()
+            rec["enc"], rec["ids"] = k["encoder_hidden_states"].clone(), k["added_time_ids"].clone()
+        return y
+    unet.forward = spy
+    steps = []
+    res = pipe(image, height=64, width=64, num_frames=4, num_inference_steps=3, latents=lat0.clone(),
+               output_type="latent", generator=torch.Generator().manual_seed(42),
+               callback_on_step_end=lambda p, i, t, kw_: (steps.append(kw_["latents"].clone()), {})[1])
+    out = {"latents0": lat0, "final": res.frames, "unet_in0": rec["in0"], "unet_out0": rec["out0"],
+           "image_embeddings": rec["enc"], "added_time_ids": rec["ids"],
+           "image_latents": rec["in0"][:, :, 4:].contiguous(),
+           "step_latents": torch.stack(steps)}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "loop.safetensors"))
+    print("loop: final std %.4f (3 steps), ids %s" % (out["final"].std(), rec["ids"].tolist()))
+
+
+def main():
+    assert os.path.isdir(REF), "runs only where /root/reference is mounted"
+    install_stubs()
+    sys.path.insert(0, REF)
+    sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
+    gen_scheduler(sched_mod)
+    ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
+                         "models.unet_spatio_temporal_condition_controlnet")
+    ref_lk = load_ref("models/unet_spatio_temporal_condition.py", "models.unet_spatio_temporal_condition")
+    gen_unet(ref_stock, ref_lk)
+    _mod("patch")
+    load_ref("patch/utils.py", "patch.utils")
+    patch_mod = load_ref("patch/patch.py", "patch.patch")
+    sys.modules["patch"].patch = patch_mod
+    gen_patch(patch_mod)
+    _mod("models"); _mod("utils")
+    sys.modules["models.unet_spatio_temporal_condition_controlnet"] = ref_stock
+    sys.modules["utils.scheduling_euler_discrete_karras_fix"] = sched_mod
+    pipe_mod = load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans")
+    gen_loop(pipe_mod, ref_stock, sched_mod)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+"""Pins the CPU oracle against fixtures produced by the reference's own code (tests/golden/make_goldens.py)."""
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import blocks as ob
+from oracle import patch_hooks as oph
+from oracle import unet as ou
+from oracle.loop import denoise
+from oracle.scheduler import EulerDiscreteOracle, SchedulerConfig
+
+WSEED = 7  # tests/golden/make_goldens.py
+
+
+def _checksum(m):
+    return float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+
+
+# ------------------------------------------------------------------------------------------------ scheduler (a2,a3)
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    with open(os.path.join(golden_dir, "scheduler_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_scheduler_tables_and_steps(kat, idx):
+    case = kat["cases"][idx]
+    s = EulerDiscreteOracle(SchedulerConfig(**kat["config"]))
+    s.set_timesteps(case["n"])
+    assert torch.equal(s.sigmas, torch.tensor(case["sigmas"]))
+    assert torch.equal(s.timesteps, torch.tensor(case["timesteps"]))
+    assert float(s.init_noise_sigma) == case["init_noise_sigma"]
+    x = torch.tensor(case["x0"]).reshape(1, 2, 4, 3, 3)
+    for t, st in zip(s.timesteps, case["steps"]):
+        v = torch.tensor(st["v"]).reshape(x.shape)
+        assert torch.equal(s.scale_model_input(x, t).flatten(), torch.tensor(st["scaled"]))
+        x = s.step(v, t, x)
+        assert torch.equal(x.flatten(), torch.tensor(st["prev"]))
+
+
+def test_scheduler_survey_kat(kat):
+    # values produced by the reference file itself
+    c25 = [c for c in kat["cases"] if c["n"] == 25][0]
+    assert c25["sigmas"][0] == 700.0 and c25["sigmas"][-1] == 0.0 and len(c25["sigmas"]) == 26
+    assert abs(c25["sigmas"][1] - 545.729248) < 1e-4 and abs(c25["sigmas"][24] - 0.002) < 1e-9
+    assert abs(c25["timesteps"][0] - 1.63777) < 1e-4 and abs(c25["timesteps"][24] + 1.553652) < 1e-4
+    assert abs(c25["init_noise_sigma"] - 700.000732) < 1e-3
+    assert abs(kat["scalar_kat"]["scaled"] - 0.0014285699) < 1e-9
+    assert abs(kat["scalar_kat"]["prev"] - 0.6694203615) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ UNet wiring (a4-a6)
+@pytest.fixture(scope="module")
+def wiring(golden_dir):
+    return load_file(os.path.join(golden_dir, "unet_wiring.safetensors"))
+
+
+def _skip_shapes(cfg, frames, hw):
+    boc = cfg.block_out_channels
+    n = 2 * frames
+    shapes = [(n, boc[0], hw, hw)]
+    r = hw
+    for i, c in enumerate(boc):
+        shapes += [(n, c, r, r)] * cfg.layers_per_block
+        if i != len(boc) - 1:
+            r //= 2
+            shapes.append((n, c, r, r))
+    return shapes, (n, boc[-1], r, r)
+
+
+def test_unet_stock_wiring(wiring):
+    m = ou.init_weights_(ou.UNetSpatioTemporalConditionControlNetModel(ou.TINY_CONFIG), WSEED)
+    assert _checksum(m) == pytest.approx(float(wiring["stock_checksum"]), rel=1e-12)
+    g = wiring
+    with torch.no_grad():
+        y = m(g["in_sample"], g["in_t"], g["in_enc"], added_time_ids=g["in_ids"], return_dict=False)[0]
+        torch.testing.assert_close(y, g["stock_out"], rtol=1e-5, atol=1e-5)
+        gg = torch.Generator().manual_seed(12)
+        shapes, mid_shape = _skip_shapes(ou.TINY_CONFIG, 4, 8)
+        down = tuple(0.1 * torch.randn(s, generator=gg) for s in shapes)
+        mid = 0.1 * torch.randn(mid_shape, generator=gg)
+        y = m(g["in_sample"], g["in_t"], g["in_enc"], down_block_additional_residuals=down,
+              mid_block_additional_residual=mid, added_time_ids=g["in_ids"], return_dict=False)[0]
+        torch.testing.assert_close(y, g["stock_out_ctrl"], rtol=1e-5, atol=1e-5)
+        y = m(g["in_sample"], 0.5, g["in_enc"], added_time_ids=g["in_ids"]).sample
+        torch.testing.assert_close(y, g["stock_out_tfloat"], rtol=1e-5, atol=1e-5)
+
+
+def test_unet_lk_wiring_and_fuse(wiring):
+    m = ou.init_weights_(ou.UNetSpatioTemporalConditionModel(ou.TINY_CONFIG), WSEED + 1)
+    assert _checksum(m) == pytest.approx(float(wiring["lk_checksum"]), rel=1e-12)
+    g = wiring
+    with torch.no_grad():
+        fused = m.lk_fuse(g["in_enc"], g["in_domain"], g["in_flow"])
+        torch.testing.assert_close(fused, g["lk_fused_enc"], rtol=1e-5, atol=1e-5)
+        y = m(g["in_sample"], g["in_t"], g["in_enc"], g["in_domain"], g["in_flow"], added_time_ids=g["in_ids"],
+              return_dict=False)[0]
+        torch.testing.assert_close(y, g["lk_out"], rtol=1e-5, atol=1e-5)
+
+
+def test_structural_parameter_count():
+    # the released SVD unet has 1 524 623 082 parameters; LK extras add 726 796
+    with torch.device("meta"):
+        a = ou.UNetSpatioTemporalConditionControlNetModel(ou.SVD_CONFIG)
+        b = ou.UNetSpatioTemporalConditionModel(ou.SVD_CONFIG)
+    na = sum(p.numel() for p in a.parameters())
+    assert na == 1_524_623_082
+    assert sum(p.numel() for p in b.parameters()) - na == 726_796
+
+
+# ------------------------------------------------------------------------------------------------ patch hooks (a14)
+class _Holder(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.spatial = ob.BasicTransformerBlock(128, 2, 64, 1024)
+        self.temporal = ob.TemporalBasicTransformerBlock(128, 128, 2, 64, 1024)
+
+
+def test_patch_joint_hooks(golden_dir):
+    g = load_file(os.path.join(golden_dir, "patch_joint.safetensors"))
+    torch.manual_seed(21)
+    h = ou.init_weights_(_Holder(), 21)
+    mask = torch.tensor([False, True, False, True])
+    x, enc, tctx = g["in_x"], g["in_enc"], g["in_tctx"]
+    with torch.no_grad():
+        for name, blk in (("spatial", h.spatial), ("temporal", h.temporal)):
+            oph.initialize_joint_layers(blk, "conv")
+            # zero-init conv1n => joint branch is the identity
+            if name == "spatial":
+                y = oph.basic_block_forward(blk, x, enc, mask, enable_joint=True)
+                torch.testing.assert_close(y, g["spatial_nojoint"], rtol=1e-5, atol=1e-5)
+            blk.conv1n.weight.copy_(g[f"conv1n_{name}"])
+            blk.attn1n.load_state_dict({k[len(f"attn1n_{name}."):]: v for k, v in g.items()
+                                        if k.startswith(f"attn1n_{name}.")})
+        y = oph.basic_block_forward(h.spatial, x, enc, mask, enable_joint=True)
+        torch.testing.assert_close(y, g["spatial_joint_noflip"], rtol=1e-5, atol=1e-5)
+        y = oph.basic_block_forward(h.spatial, x, enc, mask, enable_joint=True, flip=True, n_frames=3)
+        torch.testing.assert_close(y, g["spatial_joint_flip"], rtol=1e-5, atol=1e-5)
+        h.spatial.joint_scale = 0.5
+        y = oph.basic_block_forward(h.spatial, x, enc, mask, enable_joint=True)
+        torch.testing.assert_close(y, g["spatial_joint_scale05"], rtol=1e-5, atol=1e-5)
+        y = oph.basic_block_forward(h.spatial, x, enc, mask, enable_joint=False)
+        torch.testing.assert_close(y, g["spatial_nojoint"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(h.spatial(x, encoder_hidden_states=enc), g["spatial_nojoint"], rtol=1e-5, atol=1e-5)
+        y = oph.temporal_block_forward(h.temporal, x, 3, tctx, mask, enable_joint=True)
+        torch.testing.assert_close(y, g["temporal_joint"], rtol=1e-5, atol=1e-5)
+        y = oph.temporal_block_forward(h.temporal, x, 3, tctx, mask, enable_joint=False)
+        torch.testing.assert_close(y, g["temporal_nojoint"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(h.temporal(x, 3, tctx), g["temporal_nojoint"], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ loop (a1)
+def test_loop_against_reference_pipeline(golden_dir):
+    g = load_file(os.path.join(golden_dir, "loop.safetensors"))
+    m = ou.init_weights_(ou.UNetSpatioTemporalConditionControlNetModel(ou.TINY_CONFIG), WSEED)
+    steps = []
+    with torch.no_grad():
+        y0 = m(g["unet_in0"], EulerDiscreteOracle().timesteps[0] * 0 + 1.6377699375152588, g["image_embeddings"],
+               added_time_ids=g["added_time_ids"], return_dict=False)[0]
+        torch.testing.assert_close(y0, g["unet_out0"], rtol=1e-4, atol=1e-4)
+        out = denoise(m, EulerDiscreteOracle(), g["latents0"], g["image_latents"], g["image_embeddings"],
+                      g["added_time_ids"], 3, callback=lambda i, t, l: steps.append(l.clone()))
+    torch.testing.assert_close(torch.stack(steps), g["step_latents"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out, g["final"], rtol=1e-4, atol=1e-4)
