@@ -1,0 +1,176 @@
+/*
+ * lkgd_hip.h - C-ABI of the MI355X (gfx950) kernels behind the SVD / LKGD denoising hot path.
+ *
+ * The reference (caoql98/LKGD) is pure Python: it has no FFI of its own.  Every FLOP of its hot path is an ATen
+ * operator reached through diffusers modules, so the "interface each entry point replaces" is the ATen call made
+ * at the cited reference line (paths relative to /root/reference; [EXT] = inside diffusers==0.27.2, un-vendored,
+ * restated in oracle/blocks.py).  The Python binding a maintainer adds on the reference side is shown in
+ * INTEGRATION.md (ctypes, raw device pointers + the current HIP stream).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless named h_*; activations are fp16, channels-last:
+ *     a "token matrix" [T, C] with T = (batch*frame, y, x) row-major, C contiguous.
+ *   - no allocation, no synchronisation, no global state inside; safe on any stream; graph-capturable.
+ *   - return value: 0 = launched; negative = LKGD_E_* (nothing was launched).
+ */
+#ifndef LKGD_HIP_H
+#define LKGD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lkgd_stream_t; /* hipStream_t */
+
+enum {
+  LKGD_OK = 0,
+  LKGD_E_NULL = -1,      /* required pointer is NULL */
+  LKGD_E_SHAPE = -2,     /* shape violates the kernel's tiling contract */
+  LKGD_E_ALIGN = -3,     /* pointer / leading dimension not 16-byte aligned */
+  LKGD_E_MODE = -4,      /* unknown mode / flag */
+  LKGD_E_LAUNCH = -5     /* hipLaunchKernel reported an error */
+};
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 1. MFMA GEMM with implicit-convolution A operand and fused epilogue.
+ *
+ *    out[m, n] = s_acc * ( sum_k A(m,k) * W[n,k] + bias[n] + rowbias[idx(m), n] )
+ *                + r1 * res1[m, n] + r2 * res2[m, n]                           (fp32 accumulate, fp16 store)
+ *    with idx(m) = ((m / rb_d1) * rb_m1 + (m % rb_d2)) % rb_md
+ *    GEGLU (geglu=1): W rows are tile-interleaved [64 hidden | 64 gate]; out[m, j] = hidden * gelu_erf(gate),
+ *                     out has N/2 columns.
+ *
+ *    A(m,k) by `mode`:
+ *      LKGD_A_PLAIN     A = a0[m, k] for k < csplit else a1[m, k - csplit]        (Linear, 1x1 conv, concat input)
+ *      LKGD_A_CONV3X3   k = (ky*3+kx)*Cin + c; token m = (n, y, x) on the Hout x Wout grid reads source pixel
+ *                       ((y*stride+ky-1) >> ups, (x*stride+kx-1) >> ups) of the Hin x Win grid, zero outside
+ *                       (pad 1); ups=1 folds nearest-2x upsampling into the gather; channel c from a0 / a1 as above
+ *      LKGD_A_TCONV3    k = kt*Cin + c; token m = (b, f, s) reads frame f+kt-1 (zero outside [0,F)); Conv3d (3,1,1)
+ *      LKGD_A_CONV3X3_C8 conv3x3 with Cin == 8 (conv_in): one 16-byte chunk per tap, K padded to 128
+ *
+ *    Replaces (reference call sites):
+ *      F.linear      - attention to_q/k/v/to_out, GEGLU proj + FF out, proj_in/out, time_emb_proj
+ *                      [EXT attention.py / attention_processor.py], witnessed at patch/patch.py:440-445,543-569
+ *      F.conv2d 3x3  - models/unet_spatio_temporal_condition_controlnet.py:431 (conv_in), :500 (conv_out),
+ *                      ResnetBlock2D conv1/conv2, Downsample2D, Upsample2D [EXT resnet.py]
+ *      F.conv2d 1x1  - ResnetBlock2D.conv_shortcut [EXT]
+ *      F.conv3d      - TemporalResnetBlock conv1/conv2 (3,1,1) [EXT resnet.py]
+ *      F.gelu, residual adds, AlphaBlender - fused epilogues [EXT attention.py GEGLU, resnet.py AlphaBlender]
+ *    Contract: K % 64 == 0; for conv modes Cin % 64 == 0 and csplit % 64 == 0 (C8 mode: Cin == 8, K == 128);
+ *              N % 4 == 0 (geglu: N % 128 == 0); all leading dimensions % 8 == 0; pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------------- */
+enum { LKGD_A_PLAIN = 0, LKGD_A_CONV3X3 = 1, LKGD_A_TCONV3 = 2, LKGD_A_CONV3X3_C8 = 3 };
+
+typedef struct lkgd_gemm_desc {
+  const void* a0;      /* fp16 */
+  const void* a1;      /* fp16 or NULL */
+  const void* w;       /* fp16 [N][K] */
+  const float* bias;   /* fp32 [N] or NULL */
+  const void* rowbias; /* fp16 [*, ldrb] or NULL */
+  const void* res1;    /* fp16 [M, ldr1] or NULL */
+  const void* res2;    /* fp16 [M, ldr2] or NULL */
+  void* out;           /* fp16 [M, ldc] */
+  const void* zeros;   /* >= 16 bytes of device zeros (source of padded / out-of-image loads) */
+  int32_t M, N, K;
+  int32_t lda0, lda1, csplit;
+  int32_t mode, Cin;
+  int32_t Hout, Wout, Hin, Win, stride, ups;
+  int32_t F, HW;
+  int32_t ldrb, rb_d1, rb_m1, rb_d2, rb_md;
+  int32_t ldr1, ldr2, ldc;
+  float s_acc, r1, r2;
+  int32_t geglu;
+} lkgd_gemm_desc;
+
+int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 2. GroupNorm (32 groups) statistics + apply + SiLU on channels-last tokens.
+ *    x = cat(x0[:, :c0], x1[:, :c1]) along channels (x1 may be NULL); group g = channels [g*C/32, (g+1)*C/32).
+ *    Statistics span `rows_per_sample` consecutive tokens (spatial GN: H*W; temporal 5-D GN: F*H*W, i.e. ACROSS
+ *    frames).  stats[sample][32][2] = (mean, rstd), fp32.  `partial` is scratch of nsamples*nchunks*32*2 floats
+ *    (deterministic two-stage reduction, no atomics); nchunks is returned by lkgd_groupnorm_chunks().
+ *    Replaces: F.group_norm + F.silu - ResnetBlock2D/TemporalResnetBlock norm1/norm2,
+ *    TransformerSpatioTemporalModel.norm [EXT], conv_norm_out unet_..._controlnet.py:498-499.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_groupnorm_chunks(int64_t rows_per_sample, int32_t C);
+int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
+                         int64_t nsamples, int64_t rows_per_sample, float eps, float* partial, float* stats,
+                         lkgd_stream_t stream);
+int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
+                         int64_t nsamples, int64_t rows_per_sample, const float* stats, const float* gamma,
+                         const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 3. LayerNorm over the channel dimension of a token matrix, optional row-indexed bias added BEFORE normalising
+ *    (frame positional embedding: x + emb[idx(row)]), idx as in (1).
+ *    Replaces: F.layer_norm - BasicTransformerBlock.norm1/3, TemporalBasicTransformerBlock.norm_in/1/3
+ *    (patch/patch.py:416,556,600,610,670) and `hidden_states_mix + emb` [EXT transformer_temporal.py].
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_layernorm(const void* x, int32_t ldx, int64_t T, int32_t C, const float* gamma, const float* beta,
+                   float eps, const void* rowbias, int32_t ldrb, int32_t rb_d1, int32_t rb_m1, int32_t rb_d2,
+                   int32_t rb_md, void* out, int32_t ldo, lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 4. Spatial self-attention, head_dim 64, flash-style (online softmax, scores never materialised).
+ *    q/k/v: fp16 token matrices; head h occupies columns [h*64, h*64+64) of each; batch entry n owns rows
+ *    [n*S, (n+1)*S).  kv_batch_map (int32[nbatch], may be NULL = identity) selects which batch entry's K/V rows a
+ *    query batch attends to - the joint attention `attn1n` of patch/patch.py:466-482 is the same kernel with the
+ *    partner permutation.  scale = 1/8.
+ *    Replaces: F.scaled_dot_product_attention in AttnProcessor2_0 [EXT], BasicTransformerBlock.attn1
+ *    (patch/patch.py:440-445, 503-508).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_attn_spatial(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
+                      void* out, int32_t ldo, int32_t nbatch, int32_t S, int32_t heads, const int32_t* kv_batch_map,
+                      float scale, lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 5. Temporal self-attention: for every (batch b, pixel s, head h) attend over the F frames (F <= 32, head_dim 64).
+ *    Rows of q/k/v/out are tokens (b, f, s) - the [B*F,S,C] <-> [B*S,F,C] regroup of patch/patch.py:592-597,
+ *    682-684 is an index map here, never a copy.  kv_b_map as in (4) (temporal joint branch :616-658).
+ *    Replaces: TemporalBasicTransformerBlock.attn1 SDPA [EXT].
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_attn_temporal(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
+                       void* out, int32_t ldo, int32_t B, int32_t F, int32_t S, int32_t heads,
+                       const int32_t* kv_b_map, float scale, lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 6. Loop glue (pipeline_stable_video_diffusion_trans.py:549-553, :578-592; scheduler :264-288, :418-528).
+ *    lkgd_prepare_unet_input: latents fp16/fp32 [B,F,4,H,W] -> CFG duplicate, divide by sqrt(sigma^2+1), concat
+ *      image_latents [2B|B,F,4,H,W] on channels, emit channels-last fp16 tokens [cfg*B*F*H*W, 8].
+ *    lkgd_cfg_euler_step: noise_pred tokens [cfg*B*F*H*W, 4] (channels-last fp16) -> per-frame CFG
+ *      uncond + g[f]*(cond-uncond), v-prediction x0, Euler update in fp32, write latents [B,F,4,H,W] (same dtype
+ *      as input latents).  sigma / sigma_next are host scalars (the scheduler tables live on the host).
+ *    lkgd_tokens_to_nchw: channels-last tokens [N*H*W, C] -> [N, C, H, W] fp16 (UNet.forward return layout).
+ *    lkgd_nchw_to_tokens: the inverse for UNet.forward's `sample` argument ([N, C, H, W] -> tokens, any C<=ldo).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_prepare_unet_input(const void* latents, int32_t latents_is_f32, const void* image_latents, int32_t B,
+                            int32_t F, int32_t H, int32_t W, int32_t cfg, float sigma, void* tokens_out,
+                            lkgd_stream_t stream);
+int lkgd_cfg_euler_step(const void* noise_tokens, void* latents, int32_t latents_is_f32, const float* guidance,
+                        int32_t B, int32_t F, int32_t H, int32_t W, int32_t cfg, float sigma, float sigma_next,
+                        int32_t prediction_type /*0 eps, 1 v*/, lkgd_stream_t stream);
+int lkgd_tokens_to_nchw(const void* tokens, int32_t ld, int64_t N, int32_t C, int32_t HW, void* out,
+                        lkgd_stream_t stream);
+int lkgd_nchw_to_tokens(const void* nchw, int64_t N, int32_t C, int32_t HW, void* tokens, int32_t ld,
+                        lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 7. Small elementwise helpers used by the embedding path (unet_..._controlnet.py:406-419):
+ *    lkgd_timestep_embedding: out[i, :] = [cos(t_i * f_j), sin(t_i * f_j)], f_j = exp(-ln(1e4) j / (dim/2)), fp16 out
+ *    lkgd_silu: y = x * sigmoid(x) elementwise fp16;  lkgd_add: y = a + b elementwise fp16.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_timestep_embedding(const float* t, int32_t n, int32_t dim, void* out, int32_t ldo, lkgd_stream_t stream);
+int lkgd_silu(const void* x, void* y, int64_t n, lkgd_stream_t stream);
+int lkgd_add(const void* a, const void* b, void* y, int64_t n, lkgd_stream_t stream);
+
+/* version / build info: "lkgd_hip <n> gfx950" */
+const char* lkgd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LKGD_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of the gfx950 C-ABI library (include/lkgd_hip.h).
+
+The product path has NO fallback: if ``liblkgd_hip.so`` is missing or fails to load, every op raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C lkgd_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblkgd_hip.so")
+
+ERRORS = {-1: "LKGD_E_NULL", -2: "LKGD_E_SHAPE", -3: "LKGD_E_ALIGN", -4: "LKGD_E_MODE", -5: "LKGD_E_LAUNCH"}
+
+
+class LkgdHipError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    """struct lkgd_gemm_desc (include/lkgd_hip.h)."""
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("rowbias", C.c_void_p),
+        ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p), ("zeros", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda0", C.c_int32), ("lda1", C.c_int32), ("csplit", C.c_int32),
+        ("mode", C.c_int32), ("Cin", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+        ("stride", C.c_int32), ("ups", C.c_int32),
+        ("F", C.c_int32), ("HW", C.c_int32),
+        ("ldrb", C.c_int32), ("rb_d1", C.c_int32), ("rb_m1", C.c_int32), ("rb_d2", C.c_int32), ("rb_md", C.c_int32),
+        ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("ldc", C.c_int32),
+        ("s_acc", C.c_float), ("r1", C.c_float), ("r2", C.c_float),
+        ("geglu", C.c_int32),
+    ]
+
+
+#: every symbol include/lkgd_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    "lkgd_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
+    "lkgd_groupnorm_chunks": (_i32, [_i64, _i32]),
+    "lkgd_groupnorm_stats": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp]),
+    "lkgd_groupnorm_apply": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32,
+                                    _vp]),
+    "lkgd_layernorm": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
+                              _vp]),
+    "lkgd_attn_spatial": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),
+    "lkgd_attn_temporal": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _f32,
+                                  _vp]),
+    "lkgd_prepare_unet_input": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "lkgd_cfg_euler_step": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
+    "lkgd_tokens_to_nchw": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
+    "lkgd_nchw_to_tokens": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
+    "lkgd_timestep_embedding": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp]),
+    "lkgd_silu": (_i32, [_vp, _vp, _i64, _vp]),
+    "lkgd_add": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "lkgd_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises LkgdHipError when it is absent - there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LkgdHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C lkgd_amd/csrc` "
+                "(or __graft_entry__.build()). lkgd_amd has no CPU fallback.")
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise LkgdHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)       # AttributeError here = header / library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise LkgdHipError(f"{what} failed: {ERRORS.get(rc, rc)}")

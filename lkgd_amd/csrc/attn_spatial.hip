@@ -1,0 +1,207 @@
+// Spatial self-attention, head_dim 64, fp16 in / fp32 softmax+accumulate (include/lkgd_hip.h section 4).
+//
+// Flash-style for gfx950: one 256-thread workgroup = 4 waves x 32 query rows; K/V tiles of 64 keys are staged
+// through registers into a double-buffered LDS ring (loads for tile j+1 are issued before the MFMAs of tile j and
+// written after them: one barrier per tile).
+//   S^T = K . Q^T   "swapped" product: v_mfma_f32_32x32x16_f16 with A = K rows (ds_read_b128 from an XOR-swizzled
+//                   [key][64] image) and B = Q^T held in registers, so a lane owns ONE query column and 32 of the
+//                   tile's 64 scores: row max / row sum are 31 register ops + one cross-half shuffle.
+//   O^T += V^T . P^T  the S^T accumulator, converted to fp16 in place, IS the B operand (k = key on the lane-half /
+//                   register index); A = V^T comes from the row-major V image through ds_read_b64_tr_b16
+//                   (hardware-transposed LDS read), laid out so the 4-row x 16-col blocks are bank-conflict free.
+// Softmax scale and log2(e) are folded into one FMA feeding v_exp_f32 (exp2).
+#include "common.h"
+
+#define QBLK 128
+#define KVBLK 64
+#define ATT_LDS (2 * 2 * KVBLK * 64 * 2)  // 2 stages x (K 8 KiB + V 8 KiB)
+
+__device__ __forceinline__ int k_lds_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int v_lds_off(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __restrict__ q, int ldq,
+                                                              const half_t* __restrict__ k, int ldk,
+                                                              const half_t* __restrict__ v, int ldv,
+                                                              half_t* __restrict__ out, int ldo, int S, int heads,
+                                                              const int* __restrict__ kvmap, float scale_log2e,
+                                                              int nqb, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  // XCD-aware bijective remap: blocks of one (batch, head) stay on one XCD so K/V are served from its L2
+  int bid = blockIdx.x;
+  {
+    int xcd = bid & 7, slot = bid >> 3;
+    int qq = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + slot;
+  }
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int n = bh / heads, head = bh - n * heads;
+  const int kvn = kvmap ? kvmap[n] : n;
+
+  // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[qrow][16*ks + 8*h + 0..7]
+  const int qrow = qb * QBLK + w * 32 + l31;
+  const int qrow_c = qrow < S ? qrow : S - 1;
+  const half_t* qp = q + ((long long)n * S + qrow_c) * ldq + head * 64 + h * 8;
+  half8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(qp + ks * 16);
+
+  // ---- staging map: thread moves 16-byte chunks (row = id>>3, c = id&7), ids t and t+256, for K and for V
+  const half_t* kbase = k + (long long)kvn * S * ldk + head * 64;
+  const half_t* vbase = v + (long long)kvn * S * ldv + head * 64;
+  const int srow0 = t >> 3, sc = t & 7;
+  uint4 kr0, kr1, vr0, vr1;
+#define LOAD_TILE(tile)                                                        \
+  {                                                                            \
+    int key0_ = (tile) * KVBLK + srow0, key1_ = key0_ + 32;                    \
+    if (key0_ >= S) key0_ = S - 1; /* clamped rows are masked in the scores */ \
+    if (key1_ >= S) key1_ = S - 1;                                             \
+    kr0 = *(const uint4*)(kbase + (long long)key0_ * ldk + sc * 8);            \
+    kr1 = *(const uint4*)(kbase + (long long)key1_ * ldk + sc * 8);            \
+    vr0 = *(const uint4*)(vbase + (long long)key0_ * ldv + sc * 8);            \
+    vr1 = *(const uint4*)(vbase + (long long)key1_ * ldv + sc * 8);            \
+  }
+#define STORE_TILE(buf)                                       \
+  {                                                           \
+    char* kb_ = smem + (buf) * (2 * KVBLK * 128);             \
+    char* vb_ = kb_ + KVBLK * 128;                            \
+    *(uint4*)(kb_ + k_lds_off(srow0, sc)) = kr0;              \
+    *(uint4*)(kb_ + k_lds_off(srow0 + 32, sc)) = kr1;         \
+    *(uint4*)(vb_ + v_lds_off(srow0, sc)) = vr0;              \
+    *(uint4*)(vb_ + v_lds_off(srow0 + 32, sc)) = vr1;         \
+  }
+
+  float16_t oacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int ntiles = (S + KVBLK - 1) / KVBLK;
+  LOAD_TILE(0);
+  STORE_TILE(0);
+  __syncthreads();
+
+  // transposed-read lane constants: 16-lane group -> (h, dgrp); lane in group i -> (row q4 = i>>2, col part = i&3)
+  const int i16 = lane & 15;
+  const int dgrp = (lane >> 4) & 1;
+  const int tr_row = 4 * h + (i16 >> 2);
+  const int tr_c = dgrp * 2 + ((i16 & 3) >> 1);   // 16-byte chunk inside the 32-column d-fragment
+  const int tr_sub = (i16 & 1) * 8;
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int cur = j & 1;
+    if (j + 1 < ntiles) LOAD_TILE(j + 1);
+    const char* kb = smem + cur * (2 * KVBLK * 128);
+    const char* vb = kb + KVBLK * 128;
+
+    // ---- S^T tile: 64 keys x 32 queries per wave
+    float16_t s[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[f][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        half8_t kf = *(const half8_t*)(kb + k_lds_off(32 * f + l31, ks * 2 + h));
+        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
+      }
+    }
+    if ((j + 1) * KVBLK > S) {   // ragged last tile: mask keys >= S
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int key = j * KVBLK + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (key >= S) s[f][r] = -1e30f;
+        }
+    }
+    // ---- online softmax (per query column; the two lane halves hold disjoint keys of the same query)
+    float mx = s[0][0];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[f][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+    const float mb = m_new * scale_log2e;
+    m_run = m_new;
+    float psum = 0.f;
+    half8_t pf[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        half8_t pv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float p = __builtin_amdgcn_exp2f(fmaf(s[f][ss * 8 + e], scale_log2e, -mb));
+          psum += p;
+          pv[e] = (half_t)p;
+        }
+        pf[f][ss] = pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+    // ---- O^T += V^T . P^T : k-slot (half h, element jj) of k-step (f, ss) is key 32f + 16ss + 8(jj>>2) + 4h + (jj&3)
+#pragma unroll
+    for (int df = 0; df < 2; ++df) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          int row0 = 32 * f + 16 * ss + tr_row;
+          fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) fp16x4_t*)(vb + v_lds_off(row0, df * 4 + tr_c) + tr_sub));
+          fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) fp16x4_t*)(vb + v_lds_off(row0 + 8, df * 4 + tr_c) + tr_sub));
+          half4_t lo4 = __builtin_bit_cast(half4_t, lo), hi4 = __builtin_bit_cast(half4_t, hi);
+          half8_t vf = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+          oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[f][ss], oacc[df], 0, 0, 0);
+        }
+    }
+    if (j + 1 < ntiles) STORE_TILE(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane owns query row qrow, d = 32*df + 8*(r>>2) + 4*h + (r&3)
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < S) {
+    half_t* op = out + ((long long)n * S + qrow) * ldo + head * 64 + 4 * h;
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[df][g * 4 + e] * inv);
+        *(half4_t*)(op + 32 * df + 8 * g) = o;
+      }
+  }
+}
+
+extern "C" int lkgd_attn_spatial(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
+                                 void* out, int32_t ldo, int32_t nbatch, int32_t S, int32_t heads,
+                                 const int32_t* kv_batch_map, float scale, lkgd_stream_t stream) {
+  if (!q || !k || !v || !out) return LKGD_E_NULL;
+  if (nbatch <= 0 || S <= 0 || heads <= 0) return LKGD_E_SHAPE;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LKGD_E_ALIGN;
+  if (ldq < heads * 64 || ldk < heads * 64 || ldv < heads * 64 || ldo < heads * 64) return LKGD_E_SHAPE;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || ((uintptr_t)out & 7)) return LKGD_E_ALIGN;
+  int nqb = (S + QBLK - 1) / QBLK;
+  long long nwg = (long long)nqb * nbatch * heads;
+  if (nwg > 0x7fffffffLL) return LKGD_E_SHAPE;
+  hipLaunchKernelGGL(attn_spatial_kernel, dim3((unsigned)nwg), dim3(256), ATT_LDS, (hipStream_t)stream,
+                     (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, S, heads,
+                     kv_batch_map, scale * 1.4426950408889634f, nqb, (int)nwg);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}

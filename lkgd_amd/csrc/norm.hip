@@ -1,0 +1,268 @@
+// GroupNorm(32)+SiLU and LayerNorm on channels-last fp16 token matrices (include/lkgd_hip.h sections 2, 3).
+// HBM-bound kernels: 16-byte loads/stores, fp32 statistics, deterministic reductions (no float atomics to HBM).
+#include "common.h"
+
+#define GN_ROWS 64       // rows of one sample handled by one workgroup
+#define GN_GROUPS 32
+#define GN_MAXC 4096
+
+// thread -> (row lane rp, 16-byte column vector cv); a thread's channel set is fixed for the whole kernel
+struct GnMap {
+  int C8, rows_par, nslot;
+};
+__device__ __forceinline__ GnMap gn_map(int C) {
+  GnMap m;
+  m.C8 = C >> 3;
+  if (m.C8 <= 256) { m.rows_par = 256 / m.C8; m.nslot = 1; }
+  else { m.rows_par = 1; m.nslot = (m.C8 + 255) / 256; }
+  return m;
+}
+
+__device__ __forceinline__ half8_t gn_load(const half_t* x0, int c0, int ld0, const half_t* x1, int ld1,
+                                            long long row, int cv) {
+  int c = cv << 3;
+  if (c < c0) return *(const half8_t*)(x0 + row * ld0 + c);
+  return *(const half8_t*)(x1 + row * ld1 + (c - c0));
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, int c0, int ld0, const half_t* x1, int c1,
+                                                       int ld1, long long rows_per_sample, float* partial,
+                                                       int nchunks) {
+  __shared__ float s_sum[GN_MAXC];
+  __shared__ float s_sq[GN_MAXC];
+  const int C = c0 + c1;
+  const GnMap mp = gn_map(C);
+  const int t = threadIdx.x;
+  const int chunk = blockIdx.x;
+  const long long sample = blockIdx.y;
+  // s_sum/s_sq hold one [C] row per row-lane rp (rows_par * C <= 2048 floats, or C <= 4096 when rows_par == 1)
+  const long long r0 = (long long)chunk * GN_ROWS;
+  long long r1 = r0 + GN_ROWS;
+  if (r1 > rows_per_sample) r1 = rows_per_sample;
+  const long long base = sample * rows_per_sample;
+  for (int slot = 0; slot < mp.nslot; ++slot) {
+    int cv, rp;
+    if (mp.nslot == 1) { rp = t / mp.C8; cv = t - rp * mp.C8; if (rp >= mp.rows_par) continue; }
+    else { rp = 0; cv = t + 256 * slot; if (cv >= mp.C8) continue; }
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+#pragma unroll 4
+    for (long long r = r0 + rp; r < r1; r += mp.rows_par) {
+      half8_t v = gn_load(x0, c0, ld0, x1, ld1, base + r, cv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s_sum[rp * C + cv * 8 + e] = s[e];
+      s_sq[rp * C + cv * 8 + e] = q[e];
+    }
+  }
+  __syncthreads();
+  if (t < GN_GROUPS) {   // fixed-order reduction: deterministic
+    const int gs = C / GN_GROUPS;
+    float a = 0.f, b = 0.f;
+    for (int rp = 0; rp < mp.rows_par; ++rp)
+      for (int c = t * gs; c < (t + 1) * gs; ++c) { a += s_sum[rp * C + c]; b += s_sq[rp * C + c]; }
+    float* o = partial + ((sample * nchunks + chunk) * GN_GROUPS + t) * 2;
+    o[0] = a; o[1] = b;
+  }
+}
+
+// Both reduction stages run in a fixed order: results are bitwise reproducible.  Statistics are fp32 over fp16 data,
+// combined across chunks in fp64.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, int nchunks, double inv_count,
+                                                          float eps, float* stats) {
+  __shared__ float sh[8][GN_GROUPS][2];
+  const int t = threadIdx.x, g = t & 31, part = t >> 5;
+  const long long sample = blockIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int c = part; c < nchunks; c += 8) {
+    const float* p = partial + ((sample * nchunks + c) * GN_GROUPS + g) * 2;
+    a += p[0]; b += p[1];
+  }
+  sh[part][g][0] = (float)a; sh[part][g][1] = (float)b;
+  __syncthreads();
+  if (t < GN_GROUPS) {
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < 8; ++k) { sa += sh[k][t][0]; sb += sh[k][t][1]; }
+    double mean = sa * inv_count;
+    double var = sb * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(sample * GN_GROUPS + t) * 2 + 0] = (float)mean;
+    stats[(sample * GN_GROUPS + t) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0, int ld0, const half_t* x1, int c1,
+                                                       int ld1, long long rows_per_sample, const float* stats,
+                                                       const float* gamma, const float* beta, int silu,
+                                                       half_t* out, int ldo) {
+  const int C = c0 + c1;
+  const GnMap mp = gn_map(C);
+  const int t = threadIdx.x;
+  const long long sample = blockIdx.y;
+  const long long r0 = (long long)blockIdx.x * GN_ROWS;
+  long long r1 = r0 + GN_ROWS;
+  if (r1 > rows_per_sample) r1 = rows_per_sample;
+  const long long base = sample * rows_per_sample;
+  const int gs = C / GN_GROUPS;
+  for (int slot = 0; slot < mp.nslot; ++slot) {
+    int cv, rp;
+    if (mp.nslot == 1) { rp = t / mp.C8; cv = t - rp * mp.C8; if (rp >= mp.rows_par) continue; }
+    else { rp = 0; cv = t + 256 * slot; if (cv >= mp.C8) continue; }
+    float A[8], B[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = cv * 8 + e;
+      int g = c / gs;
+      float mean = stats[(sample * GN_GROUPS + g) * 2], rstd = stats[(sample * GN_GROUPS + g) * 2 + 1];
+      A[e] = rstd * gamma[c];
+      B[e] = beta[c] - mean * A[e];
+    }
+#pragma unroll 4
+    for (long long r = r0 + rp; r < r1; r += mp.rows_par) {
+      half8_t v = gn_load(x0, c0, ld0, x1, ld1, base + r, cv);
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[e] * A[e] + B[e];
+        if (silu) f = silu_f(f);
+        o[e] = (half_t)f;
+      }
+      *(half8_t*)(out + (base + r) * ldo + cv * 8) = o;
+    }
+  }
+}
+
+static int gn_check(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, long long nsamples,
+                    long long rows) {
+  if (!x0) return LKGD_E_NULL;
+  if (c1 > 0 && !x1) return LKGD_E_NULL;
+  int C = c0 + c1;
+  if (c0 <= 0 || c1 < 0 || C % GN_GROUPS || C % 8 || c0 % 8 || C > GN_MAXC) return LKGD_E_SHAPE;
+  if (ld0 % 8 || (c1 > 0 && ld1 % 8)) return LKGD_E_ALIGN;
+  if (!aligned16(x0) || (x1 && !aligned16(x1))) return LKGD_E_ALIGN;
+  if (nsamples <= 0 || rows <= 0 || nsamples > 65535) return LKGD_E_SHAPE;
+  return LKGD_OK;
+}
+
+extern "C" int lkgd_groupnorm_chunks(int64_t rows_per_sample, int32_t C) {
+  (void)C;
+  return (int)((rows_per_sample + GN_ROWS - 1) / GN_ROWS);
+}
+
+extern "C" int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
+                                    int64_t nsamples, int64_t rows_per_sample, float eps, float* partial,
+                                    float* stats, lkgd_stream_t stream) {
+  int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
+  if (rc) return rc;
+  if (!partial || !stats) return LKGD_E_NULL;
+  int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
+                     nchunks);
+  double inv = 1.0 / ((double)rows_per_sample * (double)((c0 + c1) / GN_GROUPS));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
+                     nchunks, inv, eps, stats);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+extern "C" int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
+                                    int64_t nsamples, int64_t rows_per_sample, const float* stats,
+                                    const float* gamma, const float* beta, int32_t silu, void* out, int32_t ldo,
+                                    lkgd_stream_t stream) {
+  int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
+  if (rc) return rc;
+  if (!stats || !gamma || !beta || !out) return LKGD_E_NULL;
+  if (ldo % 8 || !aligned16(out)) return LKGD_E_ALIGN;
+  int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, stats, gamma,
+                     beta, silu, (half_t*)out, ldo);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------- LayerNorm
+// one wave per row, up to 3 x 16-byte vectors per lane (C <= 1536); gamma/beta live in registers across rows
+#define LN_MAXV 3
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx, long long T, int C,
+                                                        const float* gamma, const float* beta, float eps,
+                                                        const half_t* rowbias, int ldrb, int d1, int m1, int d2,
+                                                        int md, half_t* out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int C8 = C >> 3;
+  float g[LN_MAXV][8], b[LN_MAXV][8];
+#pragma unroll
+  for (int v = 0; v < LN_MAXV; ++v) {
+    int cv = lane + 64 * v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      g[v][e] = cv < C8 ? gamma[cv * 8 + e] : 0.f;
+      b[v][e] = cv < C8 ? beta[cv * 8 + e] : 0.f;
+    }
+  }
+  const float invC = 1.0f / (float)C;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < T; row += (long long)gridDim.x * 4) {
+    float xv[LN_MAXV][8];
+    float s = 0.f;
+    long long idx = 0;
+    if (rowbias) idx = ((row / d1) * m1 + (row % d2)) % md;
+#pragma unroll
+    for (int v = 0; v < LN_MAXV; ++v) {
+      int cv = lane + 64 * v;
+      if (cv < C8) {
+        half8_t h = *(const half8_t*)(x + row * ldx + cv * 8);
+        if (rowbias) {
+          half8_t rb = *(const half8_t*)(rowbias + idx * ldrb + cv * 8);
+          // the reference adds in fp16 (hidden_states_mix + emb) before the norm
+          h = h + rb;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[v][e] = (float)h[e]; s += xv[v][e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[v][e] = 0.f;
+      }
+    }
+    float mean = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < LN_MAXV; ++v) {
+      int cv = lane + 64 * v;
+      if (cv < C8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = xv[v][e] - mean; q += d * d; }
+      }
+    }
+    float rstd = rsqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+    for (int v = 0; v < LN_MAXV; ++v) {
+      int cv = lane + 64 * v;
+      if (cv < C8) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((xv[v][e] - mean) * rstd * g[v][e] + b[v][e]);
+        *(half8_t*)(out + row * ldo + cv * 8) = o;
+      }
+    }
+  }
+}
+
+extern "C" int lkgd_layernorm(const void* x, int32_t ldx, int64_t T, int32_t C, const float* gamma,
+                              const float* beta, float eps, const void* rowbias, int32_t ldrb, int32_t rb_d1,
+                              int32_t rb_m1, int32_t rb_d2, int32_t rb_md, void* out, int32_t ldo,
+                              lkgd_stream_t stream) {
+  if (!x || !gamma || !beta || !out) return LKGD_E_NULL;
+  if (T <= 0 || C <= 0 || C % 8 || C > 64 * 8 * LN_MAXV) return LKGD_E_SHAPE;
+  if (ldx % 8 || ldo % 8 || !aligned16(x) || !aligned16(out)) return LKGD_E_ALIGN;
+  if (rowbias && (ldrb % 8 || !aligned16(rowbias) || rb_d1 <= 0 || rb_d2 <= 0 || rb_md <= 0)) return LKGD_E_SHAPE;
+  long long blocks = (T + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                     ldx, (long long)T, C, gamma, beta, eps, (const half_t*)rowbias, ldrb, rb_d1, rb_m1, rb_d2,
+                     rb_md, (half_t*)out, ldo);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}

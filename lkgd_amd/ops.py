@@ -1,0 +1,237 @@
+"""Torch-tensor front end of the C-ABI (device pointers + current HIP stream).  PyTorch is plumbing here: it owns
+device memory and streams; all arithmetic happens in lkgd_amd/csrc kernels.  Every function raises if a tensor is not
+a CUDA(HIP) tensor of the expected dtype - there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+A_PLAIN, A_CONV3X3, A_TCONV3, A_CONV3X3_C8 = 0, 1, 2, 3
+
+_zeros = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def zeros_page(device) -> torch.Tensor:
+    key = (device.type, device.index)
+    z = _zeros.get(key)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.float16, device=device)
+        _zeros[key] = z
+    return z
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.LkgdHipError(f"{name}: expected a GPU tensor (lkgd_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise _lib.LkgdHipError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t: torch.Tensor) -> int:
+    """row stride of a 2-D (possibly column-sliced) token matrix"""
+    assert t.dim() == 2 and t.stride(1) == 1, "token matrices must be [T, C] with contiguous channels"
+    return t.stride(0)
+
+
+RowMap = Tuple[int, int, int, int]   # (d1, m1, d2, md): idx(row) = ((row // d1) * m1 + row % d2) % md
+
+
+def rowmap_div(div: int) -> RowMap:
+    """idx = row // div"""
+    return (div, 1, 1, 1 << 30)
+
+
+def rowmap_div_mod(div: int, mod: int) -> RowMap:
+    """idx = (row // div) % mod"""
+    return (div, 1, 1, mod)
+
+
+def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int,
+         bias: Optional[torch.Tensor] = None, a1: Optional[torch.Tensor] = None, csplit: Optional[int] = None,
+         mode: int = A_PLAIN, Cin: int = 0, conv: Optional[Tuple[int, int, int, int, int, int]] = None,
+         tconv: Optional[Tuple[int, int]] = None, rowbias: Optional[torch.Tensor] = None,
+         rowmap: Optional[RowMap] = None, res1: Optional[torch.Tensor] = None, r1: float = 1.0,
+         res2: Optional[torch.Tensor] = None, r2: float = 1.0, s_acc: float = 1.0, geglu: bool = False) -> torch.Tensor:
+    """out = epilogue(A(.) @ w.T) - see include/lkgd_hip.h section 1.  ``conv`` = (Hout, Wout, Hin, Win, stride, ups);
+    ``tconv`` = (F, HW)."""
+    _req(a0, torch.float16, "a0"); _req(w, torch.float16, "w"); _req(out, torch.float16, "out")
+    d = GemmDesc()
+    d.a0, d.w, d.out = a0.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.a1 = _ptr(a1)
+    d.bias = _ptr(bias)
+    d.zeros = zeros_page(a0.device).data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda0 = _ld(a0)
+    d.lda1 = _ld(a1) if a1 is not None else 0
+    d.mode, d.Cin = mode, Cin
+    if mode == A_PLAIN:
+        d.csplit = csplit if csplit is not None else K
+    else:
+        d.csplit = csplit if csplit is not None else Cin
+    if conv is not None:
+        d.Hout, d.Wout, d.Hin, d.Win, d.stride, d.ups = conv
+    if tconv is not None:
+        d.F, d.HW = tconv
+    if rowbias is not None:
+        _req(rowbias, torch.float16, "rowbias")
+        d.rowbias, d.ldrb = rowbias.data_ptr(), _ld(rowbias)
+        d.rb_d1, d.rb_m1, d.rb_d2, d.rb_md = rowmap
+    if res1 is not None:
+        _req(res1, torch.float16, "res1")
+        d.res1, d.ldr1 = res1.data_ptr(), _ld(res1)
+    if res2 is not None:
+        _req(res2, torch.float16, "res2")
+        d.res2, d.ldr2 = res2.data_ptr(), _ld(res2)
+    d.ldc = _ld(out)
+    d.s_acc, d.r1, d.r2 = s_acc, r1, r2
+    d.geglu = 1 if geglu else 0
+    check(_lib.lib().lkgd_gemm_f16(C.byref(d), _stream()), "lkgd_gemm_f16")
+    return out
+
+
+def groupnorm_stats(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, rows_per_sample: int,
+                    eps: float) -> torch.Tensor:
+    _req(x0, torch.float16, "x0")
+    c0 = x0.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    L = _lib.lib()
+    nchunks = L.lkgd_groupnorm_chunks(rows_per_sample, c0 + c1)
+    partial = torch.empty(nsamples * nchunks * 64, dtype=torch.float32, device=x0.device)
+    stats = torch.empty(nsamples, 32, 2, dtype=torch.float32, device=x0.device)
+    check(L.lkgd_groupnorm_stats(x0.data_ptr(), c0, _ld(x0), _ptr(x1), c1, _ld(x1) if x1 is not None else 0,
+                                 nsamples, rows_per_sample, eps, partial.data_ptr(), stats.data_ptr(), _stream()),
+          "lkgd_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, rows_per_sample: int,
+                    stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
+                    out: torch.Tensor) -> torch.Tensor:
+    _req(x0, torch.float16, "x0"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    c0 = x0.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    check(_lib.lib().lkgd_groupnorm_apply(x0.data_ptr(), c0, _ld(x0), _ptr(x1), c1,
+                                          _ld(x1) if x1 is not None else 0, nsamples, rows_per_sample,
+                                          stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0,
+                                          out.data_ptr(), _ld(out), _stream()), "lkgd_groupnorm_apply")
+    return out
+
+
+def groupnorm_silu(x0, x1, nsamples, rows_per_sample, gamma, beta, eps, silu=True, out=None):
+    C_ = x0.shape[1] + (x1.shape[1] if x1 is not None else 0)
+    if out is None:
+        out = torch.empty(x0.shape[0], C_, dtype=torch.float16, device=x0.device)
+    stats = groupnorm_stats(x0, x1, nsamples, rows_per_sample, eps)
+    return groupnorm_apply(x0, x1, nsamples, rows_per_sample, stats, gamma, beta, silu, out)
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None,
+              rowbias: Optional[torch.Tensor] = None, rowmap: Optional[RowMap] = None) -> torch.Tensor:
+    _req(x, torch.float16, "x"); _req(gamma, torch.float32, "gamma")
+    T, C_ = x.shape
+    if out is None:
+        out = torch.empty(T, C_, dtype=torch.float16, device=x.device)
+    d1, m1, d2, md = rowmap if rowmap is not None else (1, 0, 1, 1)
+    check(_lib.lib().lkgd_layernorm(x.data_ptr(), _ld(x), T, C_, gamma.data_ptr(), beta.data_ptr(), eps,
+                                    _ptr(rowbias), _ld(rowbias) if rowbias is not None else 0, d1, m1, d2, md,
+                                    out.data_ptr(), _ld(out), _stream()), "lkgd_layernorm")
+    return out
+
+
+def attn_spatial(q, k, v, out, nbatch: int, S: int, heads: int, kv_batch_map: Optional[torch.Tensor] = None,
+                 scale: float = 0.125):
+    _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v")
+    check(_lib.lib().lkgd_attn_spatial(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
+                                       out.data_ptr(), _ld(out), nbatch, S, heads, _ptr(kv_batch_map), scale,
+                                       _stream()), "lkgd_attn_spatial")
+    return out
+
+
+def attn_temporal(q, k, v, out, B: int, F: int, S: int, heads: int, kv_b_map: Optional[torch.Tensor] = None,
+                  scale: float = 0.125):
+    _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v")
+    check(_lib.lib().lkgd_attn_temporal(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
+                                        out.data_ptr(), _ld(out), B, F, S, heads, _ptr(kv_b_map), scale, _stream()),
+          "lkgd_attn_temporal")
+    return out
+
+
+def prepare_unet_input(latents: torch.Tensor, image_latents: torch.Tensor, cfg: int, sigma: float) -> torch.Tensor:
+    """[B,F,4,H,W] latents (+ [cfg*B,F,4,H,W] image latents) -> channels-last tokens [cfg*B*F*H*W, 8]"""
+    B, F, _, H, W = latents.shape
+    _req(image_latents, torch.float16, "image_latents")
+    if not latents.is_cuda or latents.dtype not in (torch.float16, torch.float32):
+        raise _lib.LkgdHipError("latents must be a GPU fp16/fp32 tensor")
+    assert latents.is_contiguous() and image_latents.is_contiguous()
+    assert image_latents.shape == (cfg * B, F, 4, H, W), image_latents.shape
+    out = torch.empty(cfg * B * F * H * W, 8, dtype=torch.float16, device=latents.device)
+    check(_lib.lib().lkgd_prepare_unet_input(latents.data_ptr(), int(latents.dtype == torch.float32),
+                                             image_latents.data_ptr(), B, F, H, W, cfg, sigma, out.data_ptr(),
+                                             _stream()), "lkgd_prepare_unet_input")
+    return out
+
+
+def cfg_euler_step(noise_tokens: torch.Tensor, latents: torch.Tensor, guidance: Optional[torch.Tensor], cfg: int,
+                   sigma: float, sigma_next: float, v_prediction: bool = True) -> torch.Tensor:
+    """in-place Euler update of ``latents`` [B,F,4,H,W] from channels-last noise tokens [cfg*B*F*H*W, 4]"""
+    B, F, _, H, W = latents.shape
+    _req(noise_tokens, torch.float16, "noise_tokens")
+    assert latents.is_contiguous() and noise_tokens.is_contiguous()
+    check(_lib.lib().lkgd_cfg_euler_step(noise_tokens.data_ptr(), latents.data_ptr(),
+                                         int(latents.dtype == torch.float32), _ptr(guidance), B, F, H, W, cfg, sigma,
+                                         sigma_next, 1 if v_prediction else 0, _stream()), "lkgd_cfg_euler_step")
+    return latents
+
+
+def tokens_to_nchw(tokens: torch.Tensor, N: int, C_: int, H: int, W: int) -> torch.Tensor:
+    _req(tokens, torch.float16, "tokens")
+    out = torch.empty(N, C_, H, W, dtype=torch.float16, device=tokens.device)
+    check(_lib.lib().lkgd_tokens_to_nchw(tokens.data_ptr(), _ld(tokens), N, C_, H * W, out.data_ptr(), _stream()),
+          "lkgd_tokens_to_nchw")
+    return out
+
+
+def nchw_to_tokens(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, torch.float16, "x")
+    N, C_, H, W = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(N * H * W, C_, dtype=torch.float16, device=x.device)
+    check(_lib.lib().lkgd_nchw_to_tokens(x.data_ptr(), N, C_, H * W, out.data_ptr(), _ld(out), _stream()),
+          "lkgd_nchw_to_tokens")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    _req(t, torch.float32, "t")
+    out = torch.empty(t.numel(), dim, dtype=torch.float16, device=t.device)
+    check(_lib.lib().lkgd_timestep_embedding(t.data_ptr(), t.numel(), dim, out.data_ptr(), dim, _stream()),
+          "lkgd_timestep_embedding")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _req(x, torch.float16, "x")
+    y = torch.empty_like(x)
+    check(_lib.lib().lkgd_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "lkgd_silu")
+    return y
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _req(a, torch.float16, "a"); _req(b, torch.float16, "b")
+    y = torch.empty_like(a)
+    check(_lib.lib().lkgd_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "lkgd_add")
+    return y

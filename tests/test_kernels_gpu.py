@@ -1,0 +1,309 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch fp32 reference of the same op (CPU), on seeded
+inputs.  fp16 tolerance is stated per test.  Runs only on the MI355X box (-m gpu)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _h(x):
+    return x.to(torch.float16)
+
+
+def _close(got, ref, rtol=4e-3, what=""):
+    got, ref = got.float().cpu(), ref.float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-6
+    assert err <= rtol * scale + 2e-3, f"{what}: max abs err {err:.4g} vs scale {scale:.4g}"
+    rel = ((got - ref).norm() / (ref.norm() + 1e-12)).item()
+    assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from lkgd_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (1000, 64, 1280), (2, 1280, 320), (4032, 960, 640)])
+def test_gemm_plain_bias_residual(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    res = _h(torch.randn(M, N, generator=g))
+    ref = a.float() @ w.float().T + bias + 0.5 * res.float()
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=bias.to(DEV), res1=res.to(DEV), r1=0.5)
+    _close(out, ref, what="gemm plain")
+
+
+def test_gemm_two_source_and_blend(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K0, K1 = 520, 192, 128, 192
+    a0, a1 = _h(torch.randn(M, K0, generator=g)), _h(torch.randn(M, K1, generator=g))
+    w = _h(torch.randn(N, K0 + K1, generator=g) / 18)
+    bias = torch.randn(N, generator=g)
+    r1, r2 = _h(torch.randn(M, N, generator=g)), _h(torch.randn(M, N, generator=g))
+    alpha = 0.3
+    ref = (1 - alpha) * (torch.cat([a0, a1], 1).float() @ w.float().T + bias) + (1 - alpha) * r1.float() + alpha * r2.float()
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a0.to(DEV), w.to(DEV), out, M=M, N=N, K=K0 + K1, a1=a1.to(DEV), csplit=K0, bias=bias.to(DEV),
+             s_acc=1 - alpha, res1=r1.to(DEV), r1=1 - alpha, res2=r2.to(DEV), r2=alpha)
+    _close(out, ref, what="gemm 2-source blend")
+
+
+def test_gemm_rowbias_maps(ops):
+    g = torch.Generator().manual_seed(6)
+    B, Fr, HW, C = 2, 3, 20, 64
+    M = B * Fr * HW
+    a, w = _h(torch.randn(M, C, generator=g)), _h(torch.randn(C, C, generator=g) / 8)
+    rows = torch.arange(M)
+    for name, table_rows, rowmap, idx in [
+        ("per-frame-image", B * Fr, ops.rowmap_div(HW), rows // HW),
+        ("frame-pos", Fr, ops.rowmap_div_mod(HW, Fr), (rows // HW) % Fr),
+        ("per-batch", B, ops.rowmap_div(Fr * HW), rows // (Fr * HW)),
+        ("interleaved-0.27", B, (Fr * HW, HW, HW, B), ((rows // (Fr * HW)) * HW + rows % HW) % B),
+    ]:
+        table = _h(torch.randn(table_rows, C, generator=g))
+        ref = a.float() @ w.float().T + table.float()[idx]
+        out = torch.empty(M, C, dtype=torch.float16, device=DEV)
+        ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=C, K=C, rowbias=table.to(DEV), rowmap=rowmap)
+        _close(out, ref, what=name)
+
+
+def test_gemm_geglu(ops):
+    from lkgd_amd.packing import pack_geglu
+    g = torch.Generator().manual_seed(7)
+    M, C = 260, 128
+    a = _h(torch.randn(M, C, generator=g))
+    w = torch.randn(8 * C, C, generator=g) / C ** 0.5
+    b = torch.randn(8 * C, generator=g) * 0.1
+    wh = _h(w)
+    y = a.float() @ wh.float().T + b
+    hid, gate = y.chunk(2, dim=-1)
+    ref = hid * F.gelu(gate)
+    wp, bp = pack_geglu(w, b)
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=8 * C, K=C, bias=bp.to(DEV), geglu=True)
+    _close(out, ref, what="geglu")
+
+
+def _tokens(x):  # [N,C,H,W] -> [N*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def _untokens(t, N, H, W):
+    return t.reshape(N, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("stride,ups", [(1, 0), (2, 0), (1, 1)])
+def test_conv3x3(ops, stride, ups):
+    from lkgd_amd.packing import pack_conv3x3
+    g = torch.Generator().manual_seed(10 + stride + ups)
+    N, Cin, Cout, H, W = 3, 64, 128, 10, 12
+    x = _h(torch.randn(N, Cin, H, W, generator=g))
+    w = _h(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    Ho, Wo = ref.shape[-2:]
+    out = torch.empty(N * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+    ops.gemm(_tokens(x).to(DEV), pack_conv3x3(w).to(DEV), out, M=N * Ho * Wo, N=Cout, K=9 * Cin, bias=b.to(DEV),
+             mode=ops.A_CONV3X3, Cin=Cin, conv=(Ho, Wo, H, W, stride, ups))
+    _close(_untokens(out.cpu(), N, Ho, Wo), ref, what=f"conv3x3 s{stride} u{ups}")
+
+
+def test_conv3x3_concat_temb_residual(ops):
+    from lkgd_amd.packing import pack_conv3x3
+    g = torch.Generator().manual_seed(14)
+    N, C0, C1, Cout, H, W = 4, 64, 128, 64, 8, 8
+    x0, x1 = _h(torch.randn(N, C0, H, W, generator=g)), _h(torch.randn(N, C1, H, W, generator=g))
+    w = _h(torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 40)
+    b = torch.randn(Cout, generator=g)
+    temb = _h(torch.randn(N, Cout, generator=g))
+    ref = F.conv2d(torch.cat([x0, x1], 1).float(), w.float(), b, padding=1) + temb.float()[:, :, None, None]
+    out = torch.empty(N * H * W, Cout, dtype=torch.float16, device=DEV)
+    ops.gemm(_tokens(x0).to(DEV), pack_conv3x3(w).to(DEV), out, M=N * H * W, N=Cout, K=9 * (C0 + C1),
+             a1=_tokens(x1).to(DEV), csplit=C0, bias=b.to(DEV), mode=ops.A_CONV3X3, Cin=C0 + C1,
+             conv=(H, W, H, W, 1, 0), rowbias=temb.to(DEV), rowmap=ops.rowmap_div(H * W))
+    _close(_untokens(out.cpu(), N, H, W), ref, what="conv3x3 concat+temb")
+
+
+def test_conv_in_c8_and_conv_out(ops):
+    from lkgd_amd.packing import pack_conv3x3, pack_conv3x3_c8
+    g = torch.Generator().manual_seed(15)
+    N, H, W = 3, 9, 16
+    x = _h(torch.randn(N, 8, H, W, generator=g))
+    w = _h(torch.randn(64, 8, 3, 3, generator=g) / 72 ** 0.5)
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    out = torch.empty(N * H * W, 64, dtype=torch.float16, device=DEV)
+    ops.gemm(_tokens(x).to(DEV), pack_conv3x3_c8(w).to(DEV), out, M=N * H * W, N=64, K=128, bias=b.to(DEV),
+             mode=ops.A_CONV3X3_C8, Cin=8, conv=(H, W, H, W, 1, 0))
+    _close(_untokens(out.cpu(), N, H, W), ref, what="conv_in")
+    x = _h(torch.randn(N, 64, H, W, generator=g))
+    w = _h(torch.randn(4, 64, 3, 3, generator=g) / 24)
+    b = torch.randn(4, generator=g)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    out = torch.empty(N * H * W, 4, dtype=torch.float16, device=DEV)
+    ops.gemm(_tokens(x).to(DEV), pack_conv3x3(w).to(DEV), out, M=N * H * W, N=4, K=9 * 64, bias=b.to(DEV),
+             mode=ops.A_CONV3X3, Cin=64, conv=(H, W, H, W, 1, 0))
+    _close(_untokens(out.cpu(), N, H, W), ref, what="conv_out")
+
+
+def test_temporal_conv(ops):
+    from lkgd_amd.packing import pack_tconv3
+    g = torch.Generator().manual_seed(16)
+    B, Fr, C, H, W = 2, 5, 64, 6, 7
+    x5 = _h(torch.randn(B, C, Fr, H, W, generator=g))
+    w = _h(torch.randn(C, C, 3, 1, 1, generator=g) / (3 * C) ** 0.5)
+    b = torch.randn(C, generator=g)
+    ref5 = F.conv3d(x5.float(), w.float(), b, padding=(1, 0, 0))
+    tok = x5.permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous()
+    out = torch.empty(B * Fr * H * W, C, dtype=torch.float16, device=DEV)
+    ops.gemm(tok.to(DEV), pack_tconv3(w).to(DEV), out, M=B * Fr * H * W, N=C, K=3 * C, bias=b.to(DEV),
+             mode=ops.A_TCONV3, Cin=C, tconv=(Fr, H * W))
+    got5 = out.cpu().reshape(B, Fr, H, W, C).permute(0, 4, 1, 2, 3)
+    _close(got5, ref5, what="temporal conv")
+
+
+@pytest.mark.parametrize("C0,C1,rows,ns", [(64, 0, 100, 3), (320, 0, 576, 2), (128, 192, 77, 2), (2560, 0, 144, 1),
+                                           (640, 1280, 64, 2)])
+def test_groupnorm_silu(ops, C0, C1, rows, ns):
+    g = torch.Generator().manual_seed(C0 + C1 + rows)
+    C = C0 + C1
+    x = _h(torch.randn(ns * rows, C, generator=g) * 2 + 0.5)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.silu(F.group_norm(x.float().reshape(ns, rows, C).permute(0, 2, 1), 32, gamma, beta, 1e-5))
+    ref = ref.permute(0, 2, 1).reshape(ns * rows, C)
+    xd = x.to(DEV)
+    x0, x1 = (xd[:, :C0], xd[:, C0:]) if C1 else (xd, None)
+    out = ops.groupnorm_silu(x0, x1, ns, rows, gamma.to(DEV), beta.to(DEV), 1e-5)
+    _close(out, ref, what="groupnorm+silu")
+
+
+def test_layernorm_with_rowbias(ops):
+    g = torch.Generator().manual_seed(20)
+    for C in (64, 320, 640, 1280):
+        T, Fr, HW = 2 * 3 * 10, 3, 10
+        x = _h(torch.randn(T, C, generator=g) * 3 + 1)
+        gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+        out = ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5)
+        _close(out, ref, what=f"layernorm C={C}")
+        emb = _h(torch.randn(Fr, C, generator=g))
+        idx = (torch.arange(T) // HW) % Fr
+        ref = F.layer_norm((x + emb[idx]).float(), (C,), gamma, beta, 1e-5)
+        out = ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, rowbias=emb.to(DEV),
+                            rowmap=ops.rowmap_div_mod(HW, Fr))
+        _close(out, ref, what=f"layernorm+emb C={C}")
+
+
+@pytest.mark.parametrize("S,heads,nb", [(16, 1, 2), (64, 2, 3), (144, 2, 2), (576, 3, 2), (1024, 2, 2), (2304, 1, 1)])
+def test_attn_spatial(ops, S, heads, nb):
+    g = torch.Generator().manual_seed(S + heads)
+    C = heads * 64
+    qkv = _h(torch.randn(nb * S, 3 * C, generator=g))
+    q, k, v = (qkv[:, i * C:(i + 1) * C].float().reshape(nb, S, heads, 64).transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(nb * S, C)
+    d = qkv.to(DEV)
+    out = torch.empty(nb * S, C, dtype=torch.float16, device=DEV)
+    ops.attn_spatial(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], out, nb, S, heads)
+    _close(out, ref, what="attn spatial")
+    if nb >= 2:   # joint attention: K/V of the partner batch entry (patch/patch.py:466-468)
+        perm = torch.arange(nb).flip(0)
+        ref = F.scaled_dot_product_attention(q, k[perm], v[perm]).transpose(1, 2).reshape(nb * S, C)
+        ops.attn_spatial(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], out, nb, S, heads,
+                         kv_batch_map=perm.to(torch.int32).to(DEV))
+        _close(out, ref, what="attn spatial kv-map")
+
+
+def test_attn_spatial_large_scores(ops):
+    # forces the online-softmax rescale path: one key dominates late in the sequence
+    g = torch.Generator().manual_seed(99)
+    S, C = 320, 64
+    qkv = torch.randn(S, 3 * C, generator=g)
+    qkv[200, C:2 * C] = qkv[5, :C] * 6.0   # key 200 aligned with query 5
+    qkv = _h(qkv)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].float().reshape(1, S, 1, 64).transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S, C)
+    d = qkv.to(DEV)
+    out = torch.empty(S, C, dtype=torch.float16, device=DEV)
+    ops.attn_spatial(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], out, 1, S, 1)
+    _close(out, ref, what="attn spatial rescale")
+
+
+@pytest.mark.parametrize("B,Fr,S,heads", [(2, 14, 40, 2), (1, 4, 17, 1), (2, 25, 9, 1), (2, 3, 64, 5)])
+def test_attn_temporal(ops, B, Fr, S, heads):
+    g = torch.Generator().manual_seed(B + Fr + S)
+    C = heads * 64
+    qkv = _h(torch.randn(B * Fr * S, 3 * C, generator=g))
+
+    def split(i):
+        x = qkv[:, i * C:(i + 1) * C].float().reshape(B, Fr, S, heads, 64)
+        return x.permute(0, 2, 3, 1, 4).reshape(B * S, heads, Fr, 64)
+    ref = F.scaled_dot_product_attention(split(0), split(1), split(2))
+    ref = ref.reshape(B, S, heads, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B * Fr * S, C)
+    d = qkv.to(DEV)
+    out = torch.empty(B * Fr * S, C, dtype=torch.float16, device=DEV)
+    ops.attn_temporal(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], out, B, Fr, S, heads)
+    _close(out, ref, what="attn temporal")
+
+
+def test_loop_glue_against_oracle_scheduler(ops):
+    from oracle.scheduler import EulerDiscreteOracle
+    g = torch.Generator().manual_seed(30)
+    B, Fr, H, W = 1, 4, 6, 5
+    sch = EulerDiscreteOracle()
+    sch.set_timesteps(5)
+    lat = _h(torch.randn(B, Fr, 4, H, W, generator=g) * float(sch.init_noise_sigma))
+    img = _h(torch.randn(2 * B, Fr, 4, H, W, generator=g))
+    t = sch.timesteps[1]
+    sch._step_index = 1
+    sigma, sigma_next = float(sch.sigmas[1]), float(sch.sigmas[2])
+    # reference semantics in fp16 tensors (pipeline :549-553)
+    x = torch.cat([lat] * 2)
+    x = (x / ((sch.sigmas[1] ** 2 + 1) ** 0.5)).to(torch.float16)
+    x = torch.cat([x, img], dim=2)
+    ref_tok = x.permute(0, 1, 3, 4, 2).reshape(-1, 8)
+    tok = ops.prepare_unet_input(lat.to(DEV), img.to(DEV), 2, sigma)
+    assert torch.equal(tok.cpu(), ref_tok), "prepare_unet_input must be bit-exact"
+    noise = _h(torch.randn(2 * B, Fr, 4, H, W, generator=g))
+    gs = torch.linspace(1.0, 3.0, Fr)
+    u, c = noise.chunk(2)
+    n = u + gs.to(torch.float16)[None, :, None, None, None] * (c - u)
+    ref = sch.step(n, t, lat)
+    latd = lat.to(DEV).clone()
+    ops.cfg_euler_step(noise.permute(0, 1, 3, 4, 2).reshape(-1, 4).contiguous().to(DEV), latd, gs.to(DEV), 2, sigma,
+                       sigma_next)
+    err = (latd.cpu().float() - ref.float()).abs().max().item()
+    assert err <= 2 ** -10 * ref.abs().max().item() + 1e-3, err   # <= 1 fp16 ulp of the largest latent
+    back = ops.tokens_to_nchw(tok, 2 * B * Fr, 8, H, W)
+    assert torch.equal(back.cpu(), x.reshape(2 * B * Fr, 8, H, W))
+    assert torch.equal(ops.nchw_to_tokens(back).cpu(), ref_tok)
+
+
+def test_embedding_helpers(ops):
+    from oracle.blocks import Timesteps
+    t = torch.tensor([1.6378, -1.5537, 6.0, 127.0, 0.02])
+    ref = Timesteps(320, True, 0)(t)
+    got = ops.timestep_embedding(t.to(DEV), 320)
+    assert (got.cpu().float() - ref).abs().max() < 2e-3
+    x = _h(torch.randn(1003))
+    assert (ops.silu(x.to(DEV)[:1000]).cpu().float() - F.silu(x[:1000].float())).abs().max() < 2e-3
+
+
+def test_errors_are_loud(ops):
+    from lkgd_amd import LkgdHipError
+    a = torch.zeros(128, 100, dtype=torch.float16, device=DEV)   # K not a multiple of 64
+    w = torch.zeros(128, 100, dtype=torch.float16, device=DEV)
+    out = torch.zeros(128, 128, dtype=torch.float16, device=DEV)
+    with pytest.raises(LkgdHipError):
+        ops.gemm(a, w, out, M=128, N=128, K=100)
+    with pytest.raises(LkgdHipError):
+        ops.gemm(a.cpu(), w, out, M=128, N=128, K=64)
