@@ -1,0 +1,1034 @@
+"""Host side of the SVD / LKGD UNet for MI355X: the reference's module tree and ``forward`` signatures, with every
+tensor op of the forward executed by the gfx950 kernels of ``lkgd_amd/csrc`` (through ``lkgd_amd.ops``).
+
+Mirrors
+* /root/reference/models/unet_spatio_temporal_condition_controlnet.py:32,70-245,358-508
+  (``UNetSpatioTemporalConditionControlNetModel`` - stock signature), and
+* /root/reference/models/unet_spatio_temporal_condition.py:34,197-225,448-693
+  (``UNetSpatioTemporalConditionModel`` - LKGD signature, latent-knowledge fuse :536-595),
+and the diffusers==0.27.2 blocks those files instantiate.  Module and parameter names equal
+diffusers' so ``load_state_dict`` of a real SVD ``unet`` checkpoint works unchanged; block classes are *named*
+``BasicTransformerBlock`` / ``TemporalBasicTransformerBlock`` and expose the attributes the reference's ``patch``
+module pokes.
+
+MI355X-first design decisions:
+* activations are channels-last fp16 token matrices [N*H*W, C] end to end - the reference's NCHW<->[N,HW,C]<->
+  [B*HW,F,C] permutes are index maps inside kernels, never copies;
+* nn.Conv*/Linear/Norm layers here are PARAMETER HOLDERS (state-dict compatibility); they are never called.
+  ``prepare()`` re-lays the weights for the kernels once (K-contiguous fp16, fused QKV, tile-interleaved GEGLU,
+  all time_emb_proj of the model concatenated into one GEMM, cross-attention value path folded to one matrix);
+* the CLIP cross-attention has exactly one key/value token, so softmax == 1 and attn2 reduces to the row bias
+  to_out(to_v(e)) - computed for all 32 attn2 layers by ONE small GEMM per forward and folded into the epilogue of
+  the preceding projection (SURVEY.md finding 5);
+* residual adds, time-embedding adds, GEGLU, AlphaBlender mixes are GEMM epilogues; skip concats and nearest-2x
+  upsampling are folded into the consumers' gathers.
+No CPU / eager fallback: all ops raise off-GPU.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import LkgdHipError
+from .packing import pack_conv3x3, pack_conv3x3_c8, pack_geglu, pack_linear, pack_tconv3
+
+#: row order of the temporal cross-attention context, see SURVEY.md App. C11.  "interleaved_0_27" reproduces
+#: diffusers 0.27.x (rows (pixel, batch)-ordered against (batch, pixel)-ordered hidden rows); "batch_major" = later.
+TIME_CONTEXT_ORDER = "interleaved_0_27"
+
+#: GroupNorm eps of the res blocks per container (kept in ONE table, see oracle/blocks.py RESNET_EPS)
+RESNET_EPS = {
+    "CrossAttnDownBlockSpatioTemporal": 1e-6,
+    "DownBlockSpatioTemporal": 1e-5,
+    "UNetMidBlockSpatioTemporal": 1e-5,
+    "UpBlockSpatioTemporal": 1e-6,
+    "CrossAttnUpBlockSpatioTemporal": 1e-6,
+}
+
+
+@dataclass
+class UNetConfig:
+    """constructor keywords of the reference classes (unet_..._controlnet.py:70-96)"""
+    sample_size: Optional[int] = 96
+    in_channels: int = 8
+    out_channels: int = 4
+    down_block_types: Tuple[str, ...] = ("CrossAttnDownBlockSpatioTemporal", "CrossAttnDownBlockSpatioTemporal",
+                                         "CrossAttnDownBlockSpatioTemporal", "DownBlockSpatioTemporal")
+    up_block_types: Tuple[str, ...] = ("UpBlockSpatioTemporal", "CrossAttnUpBlockSpatioTemporal",
+                                       "CrossAttnUpBlockSpatioTemporal", "CrossAttnUpBlockSpatioTemporal")
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 768
+    layers_per_block: int = 2
+    cross_attention_dim: int = 1024
+    transformer_layers_per_block: int = 1
+    num_attention_heads: Tuple[int, ...] = (5, 10, 20, 20)
+    num_frames: int = 14
+
+
+@dataclass
+class UNetSpatioTemporalConditionOutput:
+    sample: torch.Tensor = None
+
+
+# ----------------------------------------------------------------------------------------------- execution context
+class Ctx:
+    """per-forward state: geometry, time-embedding table, cross-attention bias tables"""
+
+    def __init__(self, B: int, F: int, H: int, W: int, device):
+        self.B, self.F, self.H, self.W = B, F, H, W
+        self.device = device
+        self.temb_all: Optional[torch.Tensor] = None      # [B, sum C] fp16
+        self.xb_all: Optional[torch.Tensor] = None        # [B, sum C] fp16
+        self.spatial_partner: Optional[torch.Tensor] = None   # joint attention maps (patch API)
+        self.temporal_partner: Optional[torch.Tensor] = None
+
+    @property
+    def N(self):
+        return self.B * self.F
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+    @property
+    def T(self):
+        return self.B * self.F * self.H * self.W
+
+    def new(self, rows: int, cols: int) -> torch.Tensor:
+        return torch.empty(rows, cols, dtype=torch.float16, device=self.device)
+
+
+def _f32(p: torch.Tensor) -> torch.Tensor:
+    return p.detach().to(torch.float32).contiguous()
+
+
+class _Packed:
+    """marker base: modules that own kernel-layout copies of their weights"""
+    _pk = None
+
+    def pack(self, model: "_UNetBase"):
+        raise NotImplementedError
+
+
+# ----------------------------------------------------------------------------------------------- embeddings
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels: int, time_embed_dim: int, out_dim: Optional[int] = None):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, out_dim if out_dim is not None else time_embed_dim)
+
+    def pack(self):
+        self._pk = SimpleNamespace(w1=pack_linear(self.linear_1.weight), b1=_f32(self.linear_1.bias),
+                                   w2=pack_linear(self.linear_2.weight), b2=_f32(self.linear_2.bias))
+
+    def run(self, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x fp16 [M, in] -> linear_2(silu(linear_1(x))) (+ res)"""
+        pk = self._pk
+        M = x.shape[0]
+        h = torch.empty(M, pk.w1.shape[0], dtype=torch.float16, device=x.device)
+        ops.gemm(x, pk.w1, h, M=M, N=pk.w1.shape[0], K=pk.w1.shape[1], bias=pk.b1)
+        h = ops.silu(h)
+        out = torch.empty(M, pk.w2.shape[0], dtype=torch.float16, device=x.device)
+        ops.gemm(h, pk.w2, out, M=M, N=pk.w2.shape[0], K=pk.w2.shape[1], bias=pk.b2, res1=res)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------- attention holders
+class Attention(nn.Module):
+    """parameter holder for diffusers Attention (to_q/k/v without bias, to_out.0 with bias); head_dim must be 64"""
+
+    def __init__(self, query_dim: int, cross_attention_dim: Optional[int], heads: int, dim_head: int):
+        super().__init__()
+        if dim_head != 64:
+            raise LkgdHipError(f"lkgd_amd attention kernels are built for head_dim 64 (got {dim_head})")
+        self.inner_dim = heads * dim_head
+        self.heads = heads
+        self.out_dim = query_dim
+        self.scale = dim_head ** -0.5
+        kv = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, self.inner_dim, bias=False)
+        self.to_k = nn.Linear(kv, self.inner_dim, bias=False)
+        self.to_v = nn.Linear(kv, self.inner_dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(self.inner_dim, query_dim, bias=True), nn.Dropout(0.0)])
+
+    def pack_self(self):
+        return SimpleNamespace(
+            wqkv=torch.cat([pack_linear(self.to_q.weight), pack_linear(self.to_k.weight),
+                            pack_linear(self.to_v.weight)], dim=0).contiguous(),
+            wo=pack_linear(self.to_out[0].weight), bo=_f32(self.to_out[0].bias))
+
+    def fold_cross(self):
+        """single key/value token => attn2(x, e) == to_out(to_v(e)): returns (W_o @ W_v [C,1024] fp32, b_o)"""
+        wo = self.to_out[0].weight.detach().to(torch.float32)
+        wv = self.to_v.weight.detach().to(torch.float32)
+        return wo @ wv, _f32(self.to_out[0].bias)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim: int, dim_out: Optional[int] = None, mult: int = 4):
+        super().__init__()
+        inner = dim * mult
+        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim_out or dim)])
+
+    def pack(self):
+        wp, bp = pack_geglu(self.net[0].proj.weight.detach(), self.net[0].proj.bias.detach())
+        return SimpleNamespace(wp=wp, bp=bp, wo=pack_linear(self.net[2].weight), bo=_f32(self.net[2].bias))
+
+
+def _ff(ctx: Ctx, pk, x_norm: torch.Tensor, **epilogue) -> torch.Tensor:
+    """GEGLU feed-forward: [T,C] -> [T,4C] (fused gelu gate) -> [T,C] with the caller's epilogue"""
+    T, Cc = x_norm.shape
+    inner = pk.wo.shape[1]
+    g = ctx.new(T, inner)
+    ops.gemm(x_norm, pk.wp, g, M=T, N=2 * inner, K=Cc, bias=pk.bp, geglu=True)
+    out = ctx.new(T, pk.wo.shape[0])
+    ops.gemm(g, pk.wo, out, M=T, N=pk.wo.shape[0], K=inner, bias=pk.bo, **epilogue)
+    return out
+
+
+class BasicTransformerBlock(nn.Module):
+    """spatial transformer block (witness patch/patch.py:390-580)"""
+
+    def __init__(self, dim: int, num_attention_heads: int, attention_head_dim: int, cross_attention_dim: int):
+        super().__init__()
+        self.only_cross_attention = False
+        self.norm_type = "layer_norm"
+        self.pos_embed = None
+        self._chunk_size = None
+        self._chunk_dim = 0
+        self.norm1 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn1 = Attention(dim, None, num_attention_heads, attention_head_dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn2 = Attention(dim, cross_attention_dim, num_attention_heads, attention_head_dim)
+        self.norm3 = nn.LayerNorm(dim, eps=1e-5)
+        self.ff = FeedForward(dim)
+        # patch API state (lkgd_amd/patch.py)
+        self.enable_joint_attention = False
+        self.joint_scale = 1.0
+
+    def pack(self, model):
+        pk = SimpleNamespace(n1=(_f32(self.norm1.weight), _f32(self.norm1.bias)),
+                             n3=(_f32(self.norm3.weight), _f32(self.norm3.bias)),
+                             a1=self.attn1.pack_self(), ff=self.ff.pack())
+        pk.xoff = model._register_cross(self.attn2)
+        if hasattr(self, "attn1n"):
+            pk.a1n = self.attn1n.pack_self()
+            pk.conv1n = pack_linear(self.conv1n.weight) if hasattr(self, "conv1n") else None
+        self._pk = pk
+
+    def run(self, ctx: Ctx, h: torch.Tensor) -> torch.Tensor:
+        pk, T, Cc = self._pk, h.shape[0], h.shape[1]
+        heads = self.attn1.heads
+        ln = ops.layernorm(h, *pk.n1, 1e-5)
+        qkv = ctx.new(T, 3 * Cc)
+        ops.gemm(ln, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+        att = ctx.new(T, Cc)
+        ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, heads)
+        h1 = ctx.new(T, Cc)
+        # attn1 out-projection + residual + (attn2 == per-batch bias, norm2/Q/K are dead for one key token)
+        ops.gemm(att, pk.a1.wo, h1, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=h,
+                 rowbias=ctx.xb_all[:, pk.xoff:pk.xoff + Cc], rowmap=ops.rowmap_div(ctx.F * ctx.HW))
+        if self.enable_joint_attention and hasattr(self, "attn1n"):
+            h1 = self._joint(ctx, ln, h1)
+        ln3 = ops.layernorm(h1, *pk.n3, 1e-5)
+        return _ff(ctx, pk.ff, ln3, res1=h1)
+
+    def _joint(self, ctx: Ctx, ln: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
+        """joint attention attn1n with the partner batch entry's K/V (patch/patch.py:438-501, post == "conv")"""
+        pk, T, Cc = self._pk, ln.shape[0], ln.shape[1]
+        if getattr(self, "post", "conv") != "conv" or pk.conv1n is None:
+            raise LkgdHipError("joint attention: only post='conv' is implemented on the HIP path")
+        if ctx.spatial_partner is None:
+            raise LkgdHipError("joint attention enabled but no joint_attn_mask set (patch.set_joint_attention_mask)")
+        qkv = ctx.new(T, 3 * Cc)
+        ops.gemm(ln, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+        att = ctx.new(T, Cc)
+        ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, self.attn1n.heads,
+                         kv_batch_map=ctx.spatial_partner)
+        o1n = ctx.new(T, Cc)
+        ops.gemm(att, pk.a1n.wo, o1n, M=T, N=Cc, K=Cc, bias=pk.a1n.bo)
+        out = ctx.new(T, Cc)
+        ops.gemm(o1n, pk.conv1n, out, M=T, N=Cc, K=Cc, s_acc=float(self.joint_scale), res1=h1)
+        return out
+
+
+class TemporalBasicTransformerBlock(nn.Module):
+    """temporal transformer block (witness patch/patch.py:582-686); rows stay (b, f, s) - no regroup copies"""
+
+    def __init__(self, dim: int, time_mix_inner_dim: int, num_attention_heads: int, attention_head_dim: int,
+                 cross_attention_dim: int):
+        super().__init__()
+        if dim != time_mix_inner_dim:
+            raise LkgdHipError("TemporalBasicTransformerBlock: dim != time_mix_inner_dim is not used by SVD")
+        self.is_res = True
+        self._chunk_size = None
+        self._chunk_dim = 0
+        self.norm_in = nn.LayerNorm(dim)
+        self.ff_in = FeedForward(dim, dim_out=time_mix_inner_dim)
+        self.norm1 = nn.LayerNorm(time_mix_inner_dim)
+        self.attn1 = Attention(time_mix_inner_dim, None, num_attention_heads, attention_head_dim)
+        self.norm2 = nn.LayerNorm(time_mix_inner_dim)
+        self.attn2 = Attention(time_mix_inner_dim, cross_attention_dim, num_attention_heads, attention_head_dim)
+        self.norm3 = nn.LayerNorm(time_mix_inner_dim)
+        self.ff = FeedForward(time_mix_inner_dim)
+        self.enable_joint_attention = False
+        self.joint_scale = 1.0
+
+    def pack(self, model):
+        pk = SimpleNamespace(nin=(_f32(self.norm_in.weight), _f32(self.norm_in.bias)),
+                             n1=(_f32(self.norm1.weight), _f32(self.norm1.bias)),
+                             n3=(_f32(self.norm3.weight), _f32(self.norm3.bias)),
+                             ffin=self.ff_in.pack(), a1=self.attn1.pack_self(), ff=self.ff.pack())
+        pk.xoff = model._register_cross(self.attn2)
+        if hasattr(self, "attn1n"):
+            pk.a1n = self.attn1n.pack_self()
+            pk.conv1n = pack_linear(self.conv1n.weight) if hasattr(self, "conv1n") else None
+        self._pk = pk
+
+    def run(self, ctx: Ctx, h_s: torch.Tensor, posemb: torch.Tensor, alpha: float, order: str) -> torch.Tensor:
+        """h_s: output of the spatial block; returns alpha*h_s + (1-alpha)*temporal(h_s + posemb[f])"""
+        pk, T, Cc = self._pk, h_s.shape[0], h_s.shape[1]
+        fmap = ops.rowmap_div_mod(ctx.HW, ctx.F)
+        lnin = ops.layernorm(h_s, *pk.nin, 1e-5, rowbias=posemb, rowmap=fmap)
+        m1 = _ff(ctx, pk.ffin, lnin, res1=h_s, rowbias=posemb, rowmap=fmap)        # ff_in(norm_in(m0)) + m0
+        ln1 = ops.layernorm(m1, *pk.n1, 1e-5)
+        qkv = ctx.new(T, 3 * Cc)
+        ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+        att = ctx.new(T, Cc)
+        ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
+                          self.attn1.heads)
+        if order == "interleaved_0_27":
+            xmap = (ctx.F * ctx.HW, ctx.HW, ctx.HW, ctx.B)
+        elif order == "batch_major":
+            xmap = ops.rowmap_div(ctx.F * ctx.HW)
+        else:
+            raise ValueError(order)
+        m2 = ctx.new(T, Cc)
+        ops.gemm(att, pk.a1.wo, m2, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=m1,
+                 rowbias=ctx.xb_all[:, pk.xoff:pk.xoff + Cc], rowmap=xmap)
+        if self.enable_joint_attention and hasattr(self, "attn1n"):
+            m2 = self._joint(ctx, ln1, m2)
+        ln3 = ops.layernorm(m2, *pk.n3, 1e-5)
+        # ff(norm3(m2)) + m2, then AlphaBlender with the spatial branch - one epilogue
+        return _ff(ctx, pk.ff, ln3, s_acc=1.0 - alpha, res1=m2, r1=1.0 - alpha, res2=h_s, r2=alpha)
+
+    def _joint(self, ctx: Ctx, ln1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
+        """temporal joint branch (patch/patch.py:616-658): attn1n over the partner batch entry's frames"""
+        pk, T, Cc = self._pk, ln1.shape[0], ln1.shape[1]
+        if getattr(self, "post", "conv") != "conv" or pk.conv1n is None:
+            raise LkgdHipError("temporal joint attention: only post='conv' is implemented on the HIP path")
+        if ctx.temporal_partner is None:
+            raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
+        qkv = ctx.new(T, 3 * Cc)
+        ops.gemm(ln1, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+        att = ctx.new(T, Cc)
+        ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
+                          self.attn1n.heads, kv_b_map=ctx.temporal_partner)
+        o1n = ctx.new(T, Cc)
+        ops.gemm(att, pk.a1n.wo, o1n, M=T, N=Cc, K=Cc, bias=pk.a1n.bo)
+        out = ctx.new(T, Cc)
+        ops.gemm(o1n, pk.conv1n, out, M=T, N=Cc, K=Cc, res1=m2)     # the temporal branch ignores joint_scale
+        return out
+
+
+class AlphaBlender(nn.Module):
+    def __init__(self, alpha: float = 0.5):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.tensor([alpha], dtype=torch.float32))
+
+
+class TransformerSpatioTemporalModel(nn.Module):
+    def __init__(self, num_attention_heads: int, attention_head_dim: int, in_channels: int, num_layers: int = 1,
+                 cross_attention_dim: int = 1024):
+        super().__init__()
+        inner = num_attention_heads * attention_head_dim
+        if inner != in_channels:
+            raise LkgdHipError("TransformerSpatioTemporalModel: inner_dim != in_channels is not used by SVD")
+        self.in_channels = in_channels
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6)
+        self.proj_in = nn.Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, cross_attention_dim)
+            for _ in range(num_layers)])
+        self.temporal_transformer_blocks = nn.ModuleList([
+            TemporalBasicTransformerBlock(inner, inner, num_attention_heads, attention_head_dim, cross_attention_dim)
+            for _ in range(num_layers)])
+        self.time_pos_embed = TimestepEmbedding(in_channels, in_channels * 4, out_dim=in_channels)
+        self.time_mixer = AlphaBlender(0.5)
+        self.proj_out = nn.Linear(inner, in_channels)
+        self.time_context_order = None
+        self._posemb = {}
+
+    def pack(self, model):
+        self._pk = SimpleNamespace(gn=(_f32(self.norm.weight), _f32(self.norm.bias)),
+                                   win=pack_linear(self.proj_in.weight), bin=_f32(self.proj_in.bias),
+                                   wout=pack_linear(self.proj_out.weight), bout=_f32(self.proj_out.bias))
+        self.time_pos_embed.pack()
+        self._posemb = {}
+        self._alpha = None
+        for b in self.transformer_blocks:
+            b.pack(model)
+        for b in self.temporal_transformer_blocks:
+            b.pack(model)
+
+    def _pos(self, ctx: Ctx) -> torch.Tensor:
+        """frame positional embedding table [F, C]: step- and input-invariant -> computed once per frame count"""
+        e = self._posemb.get(ctx.F)
+        if e is None:
+            t = torch.arange(ctx.F, dtype=torch.float32, device=ctx.device)
+            e = self.time_pos_embed.run(ops.timestep_embedding(t, self.in_channels))
+            self._posemb[ctx.F] = e
+        return e
+
+    def run(self, ctx: Ctx, x: torch.Tensor) -> torch.Tensor:
+        pk, T, Cc = self._pk, x.shape[0], x.shape[1]
+        if self._alpha is None:
+            self._alpha = float(torch.sigmoid(self.time_mixer.mix_factor.detach().float()).item())
+        n = ops.groupnorm_silu(x, None, ctx.N, ctx.HW, *pk.gn, 1e-6, silu=False)
+        h = ctx.new(T, Cc)
+        ops.gemm(n, pk.win, h, M=T, N=Cc, K=Cc, bias=pk.bin)
+        posemb = self._pos(ctx)
+        order = self.time_context_order or TIME_CONTEXT_ORDER
+        for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
+            h_s = blk.run(ctx, h)
+            h = tblk.run(ctx, h_s, posemb, self._alpha, order)
+        out = ctx.new(T, Cc)
+        ops.gemm(h, pk.wout, out, M=T, N=Cc, K=Cc, bias=pk.bout, res1=x)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------- res blocks
+class ResnetBlock2D(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, eps: float):
+        super().__init__()
+        self.eps = eps
+        self.norm1 = nn.GroupNorm(32, in_channels, eps=eps)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = nn.GroupNorm(32, out_channels, eps=eps)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+
+
+class TemporalResnetBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, eps: float):
+        super().__init__()
+        self.eps = eps
+        self.norm1 = nn.GroupNorm(32, in_channels, eps=eps)
+        self.conv1 = nn.Conv3d(in_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = nn.GroupNorm(32, out_channels, eps=eps)
+        self.conv2 = nn.Conv3d(out_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
+
+
+class SpatioTemporalResBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, eps: float):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.spatial_res_block = ResnetBlock2D(in_channels, out_channels, temb_channels, eps)
+        self.temporal_res_block = TemporalResnetBlock(out_channels, out_channels, temb_channels, eps)
+        self.time_mixer = AlphaBlender(0.5)
+
+    def pack(self, model):
+        s, t = self.spatial_res_block, self.temporal_res_block
+        pk = SimpleNamespace(
+            n1=(_f32(s.norm1.weight), _f32(s.norm1.bias)), n2=(_f32(s.norm2.weight), _f32(s.norm2.bias)),
+            w1=pack_conv3x3(s.conv1.weight.detach()), b1=_f32(s.conv1.bias),
+            w2=pack_conv3x3(s.conv2.weight.detach()), b2=_f32(s.conv2.bias),
+            tn1=(_f32(t.norm1.weight), _f32(t.norm1.bias)), tn2=(_f32(t.norm2.weight), _f32(t.norm2.bias)),
+            tw1=pack_tconv3(t.conv1.weight.detach()), tb1=_f32(t.conv1.bias),
+            tw2=pack_tconv3(t.conv2.weight.detach()), tb2=_f32(t.conv2.bias),
+            eps=s.eps, teps=t.eps)
+        if s.conv_shortcut is not None:
+            pk.ws, pk.bs = pack_linear(s.conv_shortcut.weight.detach()), _f32(s.conv_shortcut.bias)
+        pk.toff_s = model._register_temb(s.time_emb_proj)
+        pk.toff_t = model._register_temb(t.time_emb_proj)
+        pk.alpha = None
+        self._pk = pk
+
+    def run(self, ctx: Ctx, x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x = cat(x0, x1) on channels (skip connection folded into the consumers' gathers)"""
+        pk = self._pk
+        if pk.alpha is None:
+            pk.alpha = float(torch.sigmoid(self.time_mixer.mix_factor.detach().float()).item())
+        T, Cin, Cout = ctx.T, self.in_channels, self.out_channels
+        c0 = x0.shape[1]
+        bmap = ops.rowmap_div(ctx.F * ctx.HW)
+        geo = (ctx.H, ctx.W, ctx.H, ctx.W, 1, 0)
+        # --- spatial ResnetBlock2D
+        n1 = ops.groupnorm_silu(x0, x1, ctx.N, ctx.HW, *pk.n1, pk.eps)
+        h = ctx.new(T, Cout)
+        ops.gemm(n1, pk.w1, h, M=T, N=Cout, K=9 * Cin, bias=pk.b1, mode=ops.A_CONV3X3, Cin=Cin, conv=geo,
+                 rowbias=ctx.temb_all[:, pk.toff_s:pk.toff_s + Cout], rowmap=bmap)
+        n2 = ops.groupnorm_silu(h, None, ctx.N, ctx.HW, *pk.n2, pk.eps)
+        if hasattr(pk, "ws"):
+            sc = ctx.new(T, Cout)
+            ops.gemm(x0, pk.ws, sc, M=T, N=Cout, K=Cin, a1=x1, csplit=c0, bias=pk.bs)
+        else:
+            sc = x0
+        s = ctx.new(T, Cout)
+        ops.gemm(n2, pk.w2, s, M=T, N=Cout, K=9 * Cout, bias=pk.b2, mode=ops.A_CONV3X3, Cin=Cout, conv=geo, res1=sc)
+        # --- TemporalResnetBlock on [B, C, F, H, W] == the same tokens; GroupNorm statistics span all F frames
+        n3 = ops.groupnorm_silu(s, None, ctx.B, ctx.F * ctx.HW, *pk.tn1, pk.teps)
+        h = ctx.new(T, Cout)
+        ops.gemm(n3, pk.tw1, h, M=T, N=Cout, K=3 * Cout, bias=pk.tb1, mode=ops.A_TCONV3, Cin=Cout,
+                 tconv=(ctx.F, ctx.HW), rowbias=ctx.temb_all[:, pk.toff_t:pk.toff_t + Cout], rowmap=bmap)
+        n4 = ops.groupnorm_silu(h, None, ctx.B, ctx.F * ctx.HW, *pk.tn2, pk.teps)
+        out = ctx.new(T, Cout)
+        # temporal = s + conv2(..); AlphaBlender: alpha*s + (1-alpha)*temporal = s + (1-alpha)*conv2(..)
+        ops.gemm(n4, pk.tw2, out, M=T, N=Cout, K=3 * Cout, bias=pk.tb2, mode=ops.A_TCONV3, Cin=Cout,
+                 tconv=(ctx.F, ctx.HW), s_acc=1.0 - pk.alpha, res1=s)
+        return out
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.channels = channels
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
+
+    def pack(self, model):
+        self._pk = SimpleNamespace(w=pack_conv3x3(self.conv.weight.detach()), b=_f32(self.conv.bias))
+
+    def run(self, ctx: Ctx, x: torch.Tensor) -> torch.Tensor:
+        C_ = self.channels
+        Ho, Wo = (ctx.H - 1) // 2 + 1, (ctx.W - 1) // 2 + 1
+        out = ctx.new(ctx.N * Ho * Wo, C_)
+        ops.gemm(x, self._pk.w, out, M=ctx.N * Ho * Wo, N=C_, K=9 * C_, bias=self._pk.b, mode=ops.A_CONV3X3, Cin=C_,
+                 conv=(Ho, Wo, ctx.H, ctx.W, 2, 0))
+        ctx.H, ctx.W = Ho, Wo
+        return out
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.channels = channels
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+    def pack(self, model):
+        self._pk = SimpleNamespace(w=pack_conv3x3(self.conv.weight.detach()), b=_f32(self.conv.bias))
+
+    def run(self, ctx: Ctx, x: torch.Tensor) -> torch.Tensor:
+        C_ = self.channels
+        Ho, Wo = ctx.H * 2, ctx.W * 2
+        out = ctx.new(ctx.N * Ho * Wo, C_)
+        ops.gemm(x, self._pk.w, out, M=ctx.N * Ho * Wo, N=C_, K=9 * C_, bias=self._pk.b, mode=ops.A_CONV3X3, Cin=C_,
+                 conv=(Ho, Wo, ctx.H, ctx.W, 1, 1))   # nearest-2x folded into the gather
+        ctx.H, ctx.W = Ho, Wo
+        return out
+
+
+# ----------------------------------------------------------------------------------------------- block containers
+class _BlockBase(nn.Module):
+    has_cross_attention = False
+
+    def pack(self, model):
+        for m in self.children():
+            for sub in (m if isinstance(m, nn.ModuleList) else [m]):
+                sub.pack(model)
+
+
+class CrossAttnDownBlockSpatioTemporal(_BlockBase):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers, transformer_layers_per_block,
+                 num_attention_heads, cross_attention_dim, add_downsample):
+        super().__init__()
+        eps = RESNET_EPS[type(self).__name__]
+        self.resnets = nn.ModuleList([
+            SpatioTemporalResBlock(in_channels if i == 0 else out_channels, out_channels, temb_channels, eps)
+            for i in range(num_layers)])
+        self.attentions = nn.ModuleList([
+            TransformerSpatioTemporalModel(num_attention_heads, out_channels // num_attention_heads, out_channels,
+                                           transformer_layers_per_block, cross_attention_dim)
+            for _ in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def run(self, ctx, h):
+        outs = []
+        for r, a in zip(self.resnets, self.attentions):
+            h = a.run(ctx, r.run(ctx, h))
+            outs.append((h, ctx.H, ctx.W))
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                h = d.run(ctx, h)
+            outs.append((h, ctx.H, ctx.W))
+        return h, outs
+
+
+class DownBlockSpatioTemporal(_BlockBase):
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers, add_downsample):
+        super().__init__()
+        eps = RESNET_EPS[type(self).__name__]
+        self.resnets = nn.ModuleList([
+            SpatioTemporalResBlock(in_channels if i == 0 else out_channels, out_channels, temb_channels, eps)
+            for i in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def run(self, ctx, h):
+        outs = []
+        for r in self.resnets:
+            h = r.run(ctx, h)
+            outs.append((h, ctx.H, ctx.W))
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                h = d.run(ctx, h)
+            outs.append((h, ctx.H, ctx.W))
+        return h, outs
+
+
+class UNetMidBlockSpatioTemporal(_BlockBase):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, temb_channels, num_layers=1, transformer_layers_per_block=1,
+                 num_attention_heads=1, cross_attention_dim=1280):
+        super().__init__()
+        eps = RESNET_EPS[type(self).__name__]
+        self.resnets = nn.ModuleList([SpatioTemporalResBlock(in_channels, in_channels, temb_channels, eps)
+                                      for _ in range(num_layers + 1)])
+        self.attentions = nn.ModuleList([
+            TransformerSpatioTemporalModel(num_attention_heads, in_channels // num_attention_heads, in_channels,
+                                           transformer_layers_per_block, cross_attention_dim)
+            for _ in range(num_layers)])
+
+    def run(self, ctx, h):
+        h = self.resnets[0].run(ctx, h)
+        for a, r in zip(self.attentions, self.resnets[1:]):
+            h = r.run(ctx, a.run(ctx, h))
+        return h
+
+
+def _up_in(i, num_layers, in_channels, prev_output_channel, out_channels):
+    res_skip = in_channels if i == num_layers - 1 else out_channels
+    res_in = prev_output_channel if i == 0 else out_channels
+    return res_in + res_skip
+
+
+class UpBlockSpatioTemporal(_BlockBase):
+    def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, num_layers, add_upsample):
+        super().__init__()
+        eps = RESNET_EPS[type(self).__name__]
+        self.resnets = nn.ModuleList([
+            SpatioTemporalResBlock(_up_in(i, num_layers, in_channels, prev_output_channel, out_channels),
+                                   out_channels, temb_channels, eps) for i in range(num_layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+    def run(self, ctx, h, skips: List[torch.Tensor]):
+        for r in self.resnets:
+            h = r.run(ctx, h, skips.pop())
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                h = u.run(ctx, h)
+        return h
+
+
+class CrossAttnUpBlockSpatioTemporal(_BlockBase):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, num_layers,
+                 transformer_layers_per_block, num_attention_heads, cross_attention_dim, add_upsample):
+        super().__init__()
+        eps = RESNET_EPS[type(self).__name__]
+        self.resnets = nn.ModuleList([
+            SpatioTemporalResBlock(_up_in(i, num_layers, in_channels, prev_output_channel, out_channels),
+                                   out_channels, temb_channels, eps) for i in range(num_layers)])
+        self.attentions = nn.ModuleList([
+            TransformerSpatioTemporalModel(num_attention_heads, out_channels // num_attention_heads, out_channels,
+                                           transformer_layers_per_block, cross_attention_dim)
+            for _ in range(num_layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+    def run(self, ctx, h, skips: List[torch.Tensor]):
+        for r, a in zip(self.resnets, self.attentions):
+            h = a.run(ctx, r.run(ctx, h, skips.pop()))
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                h = u.run(ctx, h)
+        return h
+
+
+def get_down_block(t, num_layers, in_channels, out_channels, temb_channels, add_downsample, num_attention_heads,
+                   cross_attention_dim, transformer_layers_per_block):
+    if t == "DownBlockSpatioTemporal":
+        return DownBlockSpatioTemporal(in_channels, out_channels, temb_channels, num_layers, add_downsample)
+    if t == "CrossAttnDownBlockSpatioTemporal":
+        return CrossAttnDownBlockSpatioTemporal(in_channels, out_channels, temb_channels, num_layers,
+                                                transformer_layers_per_block, num_attention_heads,
+                                                cross_attention_dim, add_downsample)
+    raise ValueError(t)
+
+
+def get_up_block(t, num_layers, in_channels, out_channels, prev_output_channel, temb_channels, add_upsample,
+                 num_attention_heads, cross_attention_dim, transformer_layers_per_block):
+    if t == "UpBlockSpatioTemporal":
+        return UpBlockSpatioTemporal(in_channels, prev_output_channel, out_channels, temb_channels, num_layers,
+                                     add_upsample)
+    if t == "CrossAttnUpBlockSpatioTemporal":
+        return CrossAttnUpBlockSpatioTemporal(in_channels, prev_output_channel, out_channels, temb_channels,
+                                              num_layers, transformer_layers_per_block, num_attention_heads,
+                                              cross_attention_dim, add_upsample)
+    raise ValueError(t)
+
+
+# ----------------------------------------------------------------------------------------------- top level
+class _UNetBase(nn.Module):
+    def __init__(self, config: Optional[UNetConfig] = None, **kw):
+        super().__init__()
+        cfg = config if config is not None else UNetConfig(**kw)
+        self.config = SimpleNamespace(**cfg.__dict__)
+        self.sample_size = cfg.sample_size
+        boc = tuple(cfg.block_out_channels)
+        n = len(cfg.down_block_types)
+        if len(cfg.up_block_types) != n or len(boc) != n:
+            raise ValueError("Must provide the same number of down/up block types and block_out_channels")
+        heads = cfg.num_attention_heads
+        heads = (heads,) * n if isinstance(heads, int) else tuple(heads)
+        if len(heads) != n:
+            raise ValueError("Must provide the same number of `num_attention_heads` as `down_block_types`")
+        cross = cfg.cross_attention_dim
+        cross = (cross,) * n if isinstance(cross, int) else tuple(cross)
+        lpb = [cfg.layers_per_block] * n if isinstance(cfg.layers_per_block, int) else list(cfg.layers_per_block)
+        tl = cfg.transformer_layers_per_block
+        tlpb = [tl] * n if isinstance(tl, int) else list(tl)
+        if cfg.in_channels != 8:
+            raise LkgdHipError("conv_in kernel path (LKGD_A_CONV3X3_C8) needs in_channels == 8")
+
+        self.conv_in = nn.Conv2d(cfg.in_channels, boc[0], 3, padding=1)
+        ted = boc[0] * 4
+        self.time_embedding = TimestepEmbedding(boc[0], ted)
+        self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, ted)
+        self.down_blocks = nn.ModuleList()
+        self.up_blocks = nn.ModuleList()
+        out_ch = boc[0]
+        for i, t in enumerate(cfg.down_block_types):
+            in_ch, out_ch = out_ch, boc[i]
+            self.down_blocks.append(get_down_block(t, lpb[i], in_ch, out_ch, ted, i != n - 1, heads[i], cross[i],
+                                                   tlpb[i]))
+        self._init_extra(cfg)
+        self.mid_block = UNetMidBlockSpatioTemporal(boc[-1], ted, transformer_layers_per_block=tlpb[-1],
+                                                    num_attention_heads=heads[-1], cross_attention_dim=cross[-1])
+        rboc, rheads = list(reversed(boc)), list(reversed(heads))
+        rlpb, rcross, rtlpb = list(reversed(lpb)), list(reversed(cross)), list(reversed(tlpb))
+        out_ch = rboc[0]
+        self.num_upsamplers = 0
+        for i, t in enumerate(cfg.up_block_types):
+            prev, out_ch = out_ch, rboc[i]
+            in_ch = rboc[min(i + 1, n - 1)]
+            self.up_blocks.append(get_up_block(t, rlpb[i] + 1, in_ch, out_ch, prev, ted, i != n - 1, rheads[i],
+                                               rcross[i], rtlpb[i]))
+            self.num_upsamplers += int(i != n - 1)
+        self.conv_norm_out = nn.GroupNorm(32, boc[0], eps=1e-5)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)
+        self._pk = None
+        self._temb_reg: List[nn.Linear] = []
+        self._cross_reg: List[Attention] = []
+
+    def _init_extra(self, cfg):
+        pass
+
+    # ---- reference API surface -----------------------------------------------------------------
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    @property
+    def attn_processors(self):
+        return {n + ".processor": "lkgd_hip" for n, m in self.named_modules() if isinstance(m, Attention)}
+
+    def set_attn_processor(self, processor):   # the HIP kernels are the only processor
+        return None
+
+    def set_default_attn_processor(self):
+        return None
+
+    def enable_forward_chunking(self, chunk_size=None, dim=0):
+        if dim not in (0, 1):
+            raise ValueError(f"Make sure to set `dim` to either 0 or 1, not {dim}")
+        return None   # memory knob of the reference; a no-op at 288 GB
+
+    def _set_gradient_checkpointing(self, module, value=False):
+        return None
+
+    # ---- weight packing ---------------------------------------------------------------------------------------
+    def _register_temb(self, lin: nn.Linear) -> int:
+        off = sum(l.out_features for l in self._temb_reg)
+        self._temb_reg.append(lin)
+        return off
+
+    def _register_cross(self, attn2: Attention) -> int:
+        off = sum(a.out_dim for a in self._cross_reg)
+        self._cross_reg.append(attn2)
+        return off
+
+    def invalidate(self):
+        """call after changing parameters in place (load_state_dict / .to() do it automatically)"""
+        self._pk = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._pk = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._pk = None
+        return r
+
+    @torch.no_grad()
+    def prepare(self):
+        """(re)build the kernel-layout weights; idempotent, runs once per weight version"""
+        if self._pk is not None:
+            return
+        if self.device.type != "cuda":
+            raise LkgdHipError("lkgd_amd UNet runs on MI355X only: move the module to cuda before forward()")
+        self._temb_reg, self._cross_reg = [], []
+        self.time_embedding.pack()
+        self.add_embedding.pack()
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            blk.pack(self)
+        pk = SimpleNamespace()
+        pk.w_in = pack_conv3x3_c8(self.conv_in.weight.detach())
+        pk.b_in = _f32(self.conv_in.bias)
+        pk.gn_out = (_f32(self.conv_norm_out.weight), _f32(self.conv_norm_out.bias))
+        pk.w_out = pack_conv3x3(self.conv_out.weight.detach())
+        pk.b_out = _f32(self.conv_out.bias)
+        # all time_emb_proj layers of the model as ONE [sum C, 1280] GEMM per step
+        pk.w_temb = torch.cat([pack_linear(l.weight) for l in self._temb_reg], dim=0).contiguous()
+        pk.b_temb = torch.cat([_f32(l.bias) for l in self._temb_reg]).contiguous()
+        # all one-token cross-attentions folded to ONE [sum C, 1024] GEMM per forward
+        folded = [a.fold_cross() for a in self._cross_reg]
+        pk.w_x = torch.cat([w for w, _ in folded], dim=0).to(torch.float16).contiguous()
+        pk.b_x = torch.cat([b for _, b in folded]).contiguous()
+        self._pk = pk
+
+    # ---- forward pieces ---------------------------------------------------------------------------------------
+    def _time_embed(self, ctx: Ctx, timestep, added_time_ids) -> None:
+        """unet_..._controlnet.py:388-426 -> table temb_all[b, :] = time_emb_proj_*(silu(emb[b]))"""
+        dev, B = ctx.device, ctx.B
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.float32, device=dev)
+        t = t.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        boc0 = self.config.block_out_channels[0]
+        emb = self.time_embedding.run(ops.timestep_embedding(t, boc0))
+        ids = added_time_ids.to(device=dev, dtype=torch.float32).flatten().contiguous()
+        if ids.numel() % B:
+            raise ValueError("added_time_ids must be [batch, n_ids]")
+        te = ops.timestep_embedding(ids, self.config.addition_time_embed_dim).reshape(B, -1)
+        emb = self.add_embedding.run(te, res=emb)                  # emb + aug_emb
+        semb = ops.silu(emb)
+        pk = self._pk
+        ctx.temb_all = torch.empty(B, pk.w_temb.shape[0], dtype=torch.float16, device=dev)
+        ops.gemm(semb, pk.w_temb, ctx.temb_all, M=B, N=pk.w_temb.shape[0], K=pk.w_temb.shape[1], bias=pk.b_temb)
+
+    def _cross_tables(self, ctx: Ctx, encoder_hidden_states: torch.Tensor) -> None:
+        if encoder_hidden_states.dim() != 3 or encoder_hidden_states.shape[1] != 1:
+            raise LkgdHipError("encoder_hidden_states must be [batch, 1, cross_attention_dim] (one CLIP image token); "
+                               "a multi-token context is outside the SVD hot path")
+        pk = self._pk
+        e = encoder_hidden_states.to(device=ctx.device, dtype=torch.float16).reshape(ctx.B, -1).contiguous()
+        ctx.xb_all = torch.empty(ctx.B, pk.w_x.shape[0], dtype=torch.float16, device=ctx.device)
+        ops.gemm(e, pk.w_x, ctx.xb_all, M=ctx.B, N=pk.w_x.shape[0], K=pk.w_x.shape[1], bias=pk.b_x)
+
+    def _joint_maps(self, ctx: Ctx):
+        """partner permutations of the patch API (patch/patch.py:454-475), computed on the host from the 4-entry mask"""
+        mask = getattr(self, "_joint_attn_mask", None)
+        if mask is None:
+            return
+        info = getattr(self, "_tome_info", None)
+        flip = bool(info and info["args"].get("flip", False))
+
+        def partner(n_rows, group):
+            m = torch.as_tensor(mask, dtype=torch.bool).repeat_interleave(n_rows // len(mask))
+            idx = torch.arange(n_rows)
+            p = torch.empty(n_rows, dtype=torch.long)
+            p[~m] = idx[m]
+            p[m] = idx[~m]
+            if group is not None:
+                p = p.reshape(-1, group).flip(1).reshape(-1)
+            return p.to(torch.int32).to(ctx.device)
+        if ctx.N % len(mask) or ctx.B % len(mask):
+            raise LkgdHipError("joint_attn_mask length must divide the UNet batch")
+        ctx.spatial_partner = partner(ctx.N, ctx.F if flip else None)
+        ctx.temporal_partner = partner(ctx.B, None)
+
+    def _run(self, sample, timestep, encoder_hidden_states, down_block_additional_residuals,
+             mid_block_additional_residual, added_time_ids):
+        """reference forward body (unet_..._controlnet.py:388-503) from the NCHW API tensors"""
+        if sample.dim() != 5:
+            raise ValueError("sample must be [batch, frames, channels, height, width]")
+        B, F, Cin, H, W = sample.shape
+        x = sample.to(device=self.device, dtype=torch.float16).reshape(B * F, Cin, H, W).contiguous()
+        tok = ops.nchw_to_tokens(x)
+        return self.forward_tokens(tok, B, F, H, W, timestep, encoder_hidden_states, added_time_ids,
+                                   down_block_additional_residuals, mid_block_additional_residual)
+
+    def _res_tokens(self, add: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        a = add.to(device=like.device, dtype=torch.float16).contiguous()
+        t = ops.nchw_to_tokens(a)
+        if t.shape != like.shape:
+            raise ValueError(f"additional residual of shape {tuple(add.shape)} does not match skip {tuple(like.shape)}")
+        return t
+
+    @torch.no_grad()
+    def forward_tokens(self, tokens: torch.Tensor, B: int, F: int, H: int, W: int, timestep, encoder_hidden_states,
+                       added_time_ids, down_block_additional_residuals=None, mid_block_additional_residual=None):
+        """channels-last entry: input tokens [B*F*H*W, 8] -> (noise tokens [B*F*H*W, 4], ctx).  This is what
+        lkgd_amd.pipeline calls between the glue kernels (no NCHW conversions inside the loop)."""
+        self.prepare()
+        ctx = Ctx(B, F, H, W, self.device)
+        pk = self._pk
+        self._time_embed(ctx, timestep, added_time_ids)
+        self._cross_tables(ctx, encoder_hidden_states)
+        self._joint_maps(ctx)
+        h = ctx.new(ctx.T, pk.w_in.shape[0])
+        ops.gemm(tokens, pk.w_in, h, M=ctx.T, N=pk.w_in.shape[0], K=128, bias=pk.b_in, mode=ops.A_CONV3X3_C8, Cin=8,
+                 conv=(H, W, H, W, 1, 0))
+        skips = [h]
+        for blk in self.down_blocks:
+            h, outs = blk.run(ctx, h)
+            skips += [o for o, _, _ in outs]
+            if down_block_additional_residuals is not None:
+                # the reference adds the ControlNet residuals INSIDE the block loop and `zip` truncates, so early
+                # skips receive their residual once per remaining down block (App. C1) - reproduced as is
+                skips = [ops.add(s, self._res_tokens(add, s))
+                         for s, add in zip(skips, down_block_additional_residuals)]
+        h = self.mid_block.run(ctx, h)
+        if mid_block_additional_residual is not None:
+            h = ops.add(h, self._res_tokens(mid_block_additional_residual, h))
+        for blk in self.up_blocks:
+            k = len(blk.resnets)
+            part, skips = skips[-k:], skips[:-k]
+            h = blk.run(ctx, h, list(part))      # .pop() takes from the end, as the reference does
+        n = ops.groupnorm_silu(h, None, ctx.N, ctx.HW, *pk.gn_out, 1e-5)
+        co, c0 = self.config.out_channels, self.config.block_out_channels[0]
+        out_tok = ctx.new(ctx.T, co)
+        ops.gemm(n, pk.w_out, out_tok, M=ctx.T, N=co, K=9 * c0, bias=pk.b_out, mode=ops.A_CONV3X3, Cin=c0,
+                 conv=(ctx.H, ctx.W, ctx.H, ctx.W, 1, 0))
+        return out_tok, ctx
+
+    def _finish(self, out_tok, ctx, B, F, return_dict):
+        co = self.config.out_channels
+        out = ops.tokens_to_nchw(out_tok, B * F, co, ctx.H, ctx.W).reshape(B, F, co, ctx.H, ctx.W)
+        if not return_dict:
+            return (out,)
+        return UNetSpatioTemporalConditionOutput(sample=out)
+
+
+class UNetSpatioTemporalConditionControlNetModel(_UNetBase):
+    """stock signature - reference models/unet_spatio_temporal_condition_controlnet.py:358-368"""
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
+                encoder_hidden_states: torch.Tensor,
+                down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
+                mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True,
+                added_time_ids: torch.Tensor = None):
+        out_tok, ctx = self._run(sample, timestep, encoder_hidden_states, down_block_additional_residuals,
+                                 mid_block_additional_residual, added_time_ids)
+        return self._finish(out_tok, ctx, sample.shape[0], sample.shape[1], return_dict)
+
+
+class QuaternionLinearAutograd(nn.Module):
+    """parameter holder for core_qnn's layer (r/i/j/k weights [in/4, out/4] + bias), SURVEY.md App. A.8"""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        i4, o4 = in_features // 4, out_features // 4
+        s = 1.0 / math.sqrt(in_features)
+        self.r_weight = nn.Parameter(torch.randn(i4, o4) * s)
+        self.i_weight = nn.Parameter(torch.randn(i4, o4) * s)
+        self.j_weight = nn.Parameter(torch.randn(i4, o4) * s)
+        self.k_weight = nn.Parameter(torch.randn(i4, o4) * s)
+        self.bias = nn.Parameter(torch.zeros(out_features))
+
+
+class UNetSpatioTemporalConditionModel(_UNetBase):
+    """LKGD signature - reference models/unet_spatio_temporal_condition.py:448-459; ``domain_features`` and
+    ``flow_features`` are positional.  The latent-knowledge fuse (:536-595) is step-invariant, so it is evaluated once
+    per distinct (embedding, domain, flow) triple and cached (lkgd_amd/lk_fuse.py)."""
+
+    def _init_extra(self, cfg):
+        def dw():
+            return nn.Conv1d(1024, 256, kernel_size=1, groups=256, bias=False)
+        self.quaternion_lora_dconv = dw()
+        self.quaternion_lora_lconv = dw()
+        self.quaternion_lora_fconv = dw()
+        self.quaternion_lora_fuse = QuaternionLinearAutograd(1024, 512)
+        self.quaternion_lora_fuse_fft_mag = QuaternionLinearAutograd(512, 256)
+        self.quaternion_lora_fuse_fft_pha = QuaternionLinearAutograd(512, 256)
+        self.quaternion_lora_fuse_fft_mag0 = nn.Linear(4, 1)
+        self.quaternion_lora_fuse_fft_pha0 = nn.Linear(4, 1)
+        self.quaternion_lora_fuse_sf = nn.Sequential(nn.Linear(1024, 256), nn.LeakyReLU(0.1, inplace=True),
+                                                     nn.Linear(256, 1024))
+        self.quaternion_lora_texts = nn.Parameter(torch.zeros(256))
+        self.quaternion_lora_texts_fft_mag = nn.Parameter(torch.zeros(129))
+        self.quaternion_lora_texts_fft_pha = nn.Parameter(torch.zeros(129))
+        self._lk_cache = None
+
+    def invalidate(self):
+        super().invalidate()
+        self._lk_cache = None
+
+    def fused_embedding(self, encoder_hidden_states, domain_features, flow_features) -> torch.Tensor:
+        from .lk_fuse import lk_fuse_cached
+        return lk_fuse_cached(self, encoder_hidden_states, domain_features, flow_features)
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states, domain_features, flow_features,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, return_dict: bool = True,
+                added_time_ids=None):
+        enc = self.fused_embedding(encoder_hidden_states, domain_features, flow_features)
+        out_tok, ctx = self._run(sample, timestep, enc, down_block_additional_residuals,
+                                 mid_block_additional_residual, added_time_ids)
+        return self._finish(out_tok, ctx, sample.shape[0], sample.shape[1], return_dict)
+
+
+def init_synthetic_weights_(model: nn.Module, seed: int = 0) -> nn.Module:
+    """random-init for benchmarking on the device the model lives on (there are no checkpoints on the GPU box):
+    zero-mean fan-in normal weights, norm affine ~ (1, 0) with small noise, small biases."""
+    dev = next(model.parameters()).device
+    g = torch.Generator(device=dev).manual_seed(seed)
+
+    def rn(p, scale=1.0, shift=0.0):
+        p.copy_((torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) * scale + shift).to(p.dtype))
+
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (nn.GroupNorm, nn.LayerNorm)):
+                rn(m.weight, 0.1, 1.0)
+                rn(m.bias, 0.1)
+            elif isinstance(m, (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d)):
+                rn(m.weight, 1.0 / m.weight[0].numel() ** 0.5)
+                if m.bias is not None:
+                    rn(m.bias, 0.02)
+            elif isinstance(m, QuaternionLinearAutograd):
+                for w in (m.r_weight, m.i_weight, m.j_weight, m.k_weight):
+                    rn(w, 1.0 / (w.shape[0] * 4) ** 0.5)
+                rn(m.bias, 0.02)
+        for name, p in model.named_parameters():
+            if name.endswith("mix_factor") or name.startswith("quaternion_lora_texts"):
+                rn(p)
+    if hasattr(model, "invalidate"):
+        model.invalidate()
+    return model

@@ -1,0 +1,125 @@
+"""Whole-UNet parity on the MI355X: lkgd_amd (HIP kernels through the C-ABI) vs the fp32 CPU oracle and vs the golden
+fixtures produced by the reference's own ``forward`` (tests/golden/unet_wiring.safetensors).
+
+Stated fp16 tolerance: single UNet forward on unit-variance inputs - relative L2 <= 1e-2 and
+max-abs <= 5e-2 against the fp32 oracle."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+WSEED = 7
+
+
+def _gate(got, ref, what, rel_tol=1e-2, abs_tol=5e-2):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    mx = (got - ref).abs().max().item()
+    assert rel <= rel_tol and mx <= abs_tol, f"{what}: rel L2 {rel:.3e} (<= {rel_tol}), max abs {mx:.3e} (<= {abs_tol})"
+    return rel, mx
+
+
+def _pair(lk: bool, seed: int, round_weights: bool = True):
+    from oracle import unet as ou
+    from lkgd_amd import unet as pu
+    ocls = ou.UNetSpatioTemporalConditionModel if lk else ou.UNetSpatioTemporalConditionControlNetModel
+    pcls = pu.UNetSpatioTemporalConditionModel if lk else pu.UNetSpatioTemporalConditionControlNetModel
+    o = ou.init_weights_(ocls(ou.TINY_CONFIG), seed)
+    if round_weights:
+        with torch.no_grad():
+            for p in o.parameters():
+                p.copy_(p.half().float())
+    m = pcls(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    m.load_state_dict(o.state_dict(), strict=True)
+    return o, m.half().to(DEV)
+
+
+@pytest.fixture(scope="module")
+def wiring(golden_dir):
+    return load_file(os.path.join(golden_dir, "unet_wiring.safetensors"))
+
+
+def test_stock_forward_vs_oracle_and_golden(wiring):
+    g = wiring
+    o, m = _pair(False, WSEED)
+    with torch.no_grad():
+        ref = o(g["in_sample"], g["in_t"], g["in_enc"], added_time_ids=g["in_ids"], return_dict=False)[0]
+    out = m(g["in_sample"].to(DEV), g["in_t"].to(DEV), g["in_enc"].to(DEV), added_time_ids=g["in_ids"].to(DEV),
+            return_dict=False)[0]
+    assert out.shape == ref.shape and out.dtype == torch.float16
+    _gate(out, ref, "stock vs oracle(fp16-rounded weights)")
+    _gate(out, g["stock_out"], "stock vs golden from the reference forward")
+    # python-float timestep takes the promotion branch of the reference (:390-404)
+    out = m(g["in_sample"].to(DEV), 0.5, g["in_enc"].to(DEV), added_time_ids=g["in_ids"].to(DEV)).sample
+    _gate(out, g["stock_out_tfloat"], "float timestep vs golden")
+
+
+def test_controlnet_residual_quirk(wiring):
+    from test_oracle_golden import _skip_shapes
+    from oracle import unet as ou
+    g = wiring
+    _, m = _pair(False, WSEED)
+    gg = torch.Generator().manual_seed(12)
+    shapes, mid_shape = _skip_shapes(ou.TINY_CONFIG, 4, 8)
+    down = tuple((0.1 * torch.randn(s, generator=gg)).to(DEV) for s in shapes)
+    mid = (0.1 * torch.randn(mid_shape, generator=gg)).to(DEV)
+    out = m(g["in_sample"].to(DEV), g["in_t"].to(DEV), g["in_enc"].to(DEV), down_block_additional_residuals=down,
+            mid_block_additional_residual=mid, added_time_ids=g["in_ids"].to(DEV), return_dict=False)[0]
+    _gate(out, g["stock_out_ctrl"], "ControlNet residuals (repeated-add quirk) vs golden")
+
+
+def test_lk_forward_and_fused_embedding(wiring):
+    g = wiring
+    o, m = _pair(True, WSEED + 1)
+    fused = m.fused_embedding(g["in_enc"].to(DEV), g["in_domain"].to(DEV), g["in_flow"].to(DEV))
+    _gate(fused, g["lk_fused_enc"], "LK fused embedding vs golden", rel_tol=2e-3, abs_tol=1e-2)
+    out = m(g["in_sample"].to(DEV), g["in_t"].to(DEV), g["in_enc"].to(DEV), g["in_domain"].to(DEV),
+            g["in_flow"].to(DEV), added_time_ids=g["in_ids"].to(DEV), return_dict=False)[0]
+    _gate(out, g["lk_out"], "LK forward vs golden")
+    # hoisting: the second call must reuse the cached fuse
+    assert m.fused_embedding(g["in_enc"].to(DEV), g["in_domain"].to(DEV), g["in_flow"].to(DEV)) is not None
+
+
+def test_time_context_order_switch(wiring):
+    """App. C11: the two row orders of the temporal cross-attention context differ under CFG; both match the oracle"""
+    from oracle import blocks as ob
+    g = wiring
+    o, m = _pair(False, WSEED)
+    for order in ("interleaved_0_27", "batch_major"):
+        for mod in o.modules():
+            if isinstance(mod, ob.TransformerSpatioTemporalModel):
+                mod.time_context_order = order
+        for mod in m.modules():
+            if type(mod).__name__ == "TransformerSpatioTemporalModel":
+                mod.time_context_order = order
+        with torch.no_grad():
+            ref = o(g["in_sample"], g["in_t"], g["in_enc"], added_time_ids=g["in_ids"], return_dict=False)[0]
+        out = m(g["in_sample"].to(DEV), g["in_t"].to(DEV), g["in_enc"].to(DEV), added_time_ids=g["in_ids"].to(DEV),
+                return_dict=False)[0]
+        _gate(out, ref, f"time_context_order={order}")
+
+
+def test_odd_shapes_frames_and_rect(wiring):
+    """ragged cases: 3 frames, non-square 8x16 latent (S = 128, 32, 8, 2 tokens at the four levels)"""
+    o, m = _pair(False, 3)
+    gg = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 8, 8, 16, generator=gg)
+    enc = torch.randn(2, 1, 1024, generator=gg)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    t = torch.tensor(-0.7)
+    with torch.no_grad():
+        ref = o(x, t, enc, added_time_ids=ids, return_dict=False)[0]
+    out = m(x.to(DEV), t.to(DEV), enc.to(DEV), added_time_ids=ids.to(DEV), return_dict=False)[0]
+    _gate(out, ref, "3 frames, 8x16")
+
+
+def test_no_cpu_path():
+    from lkgd_amd import LkgdHipError
+    from lkgd_amd import unet as pu
+    from oracle import unet as ou
+    m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    with pytest.raises(LkgdHipError):
+        m(torch.zeros(1, 2, 8, 8, 8), 1.0, torch.zeros(1, 1, 1024), added_time_ids=torch.zeros(1, 3))
