@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoised frames/sec of the SVD Euler loop (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one clip of synthetic input: the full 25-step Euler sampling loop over the
+real-shaped SVD UNet (random-init, fp16) for 14 frames x 576x1024 (latents 72x128), CFG on, inputs resident in HBM,
+``output_type="latent"`` (CLIP / VAE are boundary stages and excluded).  value = frames of all K timed
+clips / wall time (max over ranks).  With N > 1 the frames of the ONE clip are sharded over the ranks
+(lkgd_amd/dist.py: CFG-parallel x frame slices, RCCL) - strong scaling.
+
+Prints ONE JSON line on rank 0, with
+  roofline     - the dominant kernel (the MFMA GEMM / implicit-conv kernel): algorithmic TFLOP/s measured live with
+                 HIP events around every launch inside the timed region, against the dense fp16 MFMA peak;
+  cpu_baseline - the fp32 CPU oracle (oracle/, "port") timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+UNET_TFLOP_C2 = 89.69         # algorithmic TFLOP of one UNet forward at C2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed clips")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed clips")
+    ap.add_argument("--frames", type=int, default=14)
+    ap.add_argument("--height", type=int, default=576)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--inference-steps", type=int, default=25)
+    ap.add_argument("--tiny", action="store_true", help="tiny UNet config (plumbing checks only; not a valid number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_inputs(dev, frames, h, w):
+    """SURVEY.md 8d / BASELINE.md 2.1"""
+    def rn(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+    lat0 = rn((1, frames, 4, h, w), 12345)
+    img = rn((1, 4, h, w), 12346) * 0.18215
+    img = torch.cat([torch.zeros_like(img), img]).unsqueeze(1).repeat(1, frames, 1, 1, 1)
+    emb = torch.cat([torch.zeros(1, 1, 1024), rn((1, 1, 1024), 12347)])
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    return lat0.to(dev), img.half().to(dev).contiguous(), emb.half().to(dev), ids.to(dev)
+
+
+def build_unet(dev, tiny):
+    from lkgd_amd import unet as pu
+    if tiny:
+        cfg = pu.UNetConfig(sample_size=8, block_out_channels=(64, 128, 128, 128), num_attention_heads=(1, 2, 2, 2),
+                            addition_time_embed_dim=64, projection_class_embeddings_input_dim=192, num_frames=4)
+    else:
+        cfg = pu.UNetConfig()
+    with torch.device("meta"):
+        m = pu.UNetSpatioTemporalConditionControlNetModel(cfg)
+    m = m.to(torch.float16).to_empty(device=dev)
+    pu.init_synthetic_weights_(m, seed=0)
+    m.prepare()
+    return m
+
+
+def cpu_baseline(args):
+    """fp32 oracle on the host cores, bounded sample: ONE forward of the real-shaped UNet on the C1 geometry
+    (CFG batch 2 x 4 frames x 32x32 latent = 2.37 algorithmic TFLOP), extrapolated to the C2 metric by FLOPs."""
+    from oracle import unet as ou
+    t0 = time.time()
+    with torch.device("meta"):
+        o = ou.UNetSpatioTemporalConditionControlNetModel(ou.SVD_CONFIG if not args.tiny else ou.TINY_CONFIG)
+    o = o.to_empty(device="cpu")
+    with torch.no_grad():
+        for p in o.parameters():
+            if p.ndim >= 2:
+                p.normal_(0.0, 1.0 / p[0].numel() ** 0.5)
+            else:
+                p.fill_(0.0)
+        for m in o.modules():
+            if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)):
+                m.weight.fill_(1.0)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 8, 32, 32, generator=g)
+    enc = torch.randn(2, 1, 1024, generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    t_build = time.time() - t0
+    t0 = time.time()
+    with torch.no_grad():
+        o(x, torch.tensor(1.0), enc, added_time_ids=ids, return_dict=False)
+    dt = time.time() - t0
+    tflop_sample = 2.37 if not args.tiny else 0.0
+    cores = torch.get_num_threads()
+    if args.tiny:
+        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "tiny config (invalid)"}
+    tflops = tflop_sample / dt
+    fps = args.frames / (args.inference_steps * UNET_TFLOP_C2 / tflops)
+    return {"value": round(fps, 6), "unit": "frames/s (C2-equivalent, extrapolated by algorithmic FLOPs)",
+            "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 (torch eager), one UNet forward of the real-shaped SVD UNet at CFG-batch 2 x 4 frames "
+                      f"x 32x32 latent (config 1 geometry, 2.37 TFLOP) in {dt:.1f} s = {tflops:.3f} TFLOP/s on {cores} "
+                      f"threads (os.cpu_count={os.cpu_count()}); model build {t_build:.0f} s not counted"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lkgd_amd import ops
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+
+    h, w = args.height // 8, args.width // 8
+    unet = build_unet(dev, args.tiny)
+    pipe = StableVideoDiffusionPipeline(unet=unet)
+    lat0, img, emb, ids = synthetic_inputs(dev, args.frames, h, w)
+    pipe.scheduler.set_timesteps(args.inference_steps)
+    sigma0 = float(pipe.scheduler.init_noise_sigma)
+
+    if distributed:
+        from lkgd_amd.dist_run import DistDenoiser
+        runner = DistDenoiser(pipe, world, rank, args.frames)
+
+        def one_clip():
+            return runner.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0)
+    else:
+        def one_clip():
+            return pipe.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0)
+
+    def barrier():
+        if distributed:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_clip()
+    if not args.no_kernel_events:
+        ops.GEMM_EVENTS = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_clip()
+    barrier()
+    dt = time.perf_counter() - t0
+    events = ops.GEMM_EVENTS
+    ops.GEMM_EVENTS = None
+    if distributed:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    finite = bool(torch.isfinite(out.float()).all().item())
+
+    roofline = None
+    if events:
+        tot_ms = sum(s.elapsed_time(e) for s, e, _ in events)
+        tot_flop = sum(f for _, _, f in events)
+        achieved = tot_flop / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_kernel", "achieved": round(achieved, 2),
+                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches": len(events),
+                    "avg_launch_us": round(tot_ms * 1e3 / len(events), 2),
+                    "gemm_share_of_wall": round(tot_ms * 1e-3 / dt, 3)}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args)
+        fps = args.steps * args.frames / dt
+        line = {
+            "metric": "denoised frames/sec (14f x 576x1024, 25-step Euler)", "value": round(fps, 4),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"SVD {args.frames} frames x {args.height}x{args.width}, "
+                                   f"{args.inference_steps} Euler steps, CFG 1.0->3.0, single clip, "
+                                   "vanilla pipeline_stable_video_diffusion_trans loop (configs[1])"
+                                   + (" [TINY UNET - INVALID]" if args.tiny else ""),
+                       "unet": "random-init SVD shapes (320,640,1280,1280), heads (5,10,20,20), 1.52 B params",
+                       "parallelism": "single GPU" if world == 1 else f"cfg x frame shards over {world} GPUs"},
+            "finite_output": finite,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if distributed:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

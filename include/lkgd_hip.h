@@ -167,6 +167,15 @@ int lkgd_timestep_embedding(const float* t, int32_t n, int32_t dim, void* out, i
 int lkgd_silu(const void* x, void* y, int64_t n, lkgd_stream_t stream);
 int lkgd_add(const void* a, const void* b, void* y, int64_t n, lkgd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * 8. Stand-alone scheduler ops for callers that use EulerDiscreteScheduler.scale_model_input / .step directly
+ *    (utils/scheduling_euler_discrete_karras_fix.py:264-288, :418-528) on tensors of any shape (n elements).
+ *    lkgd_scale: y = fp16(x * s).  lkgd_euler_step: prev = fp16(Euler(model_output fp16, sample fp16|fp32)).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_scale(const void* x, void* y, int64_t n, float s, lkgd_stream_t stream);
+int lkgd_euler_step(const void* model_output, const void* sample, int32_t sample_is_f32, void* prev, int64_t n,
+                    float sigma, float sigma_next, int32_t prediction_type, lkgd_stream_t stream);
+
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
 

@@ -56,6 +56,8 @@ SYMBOLS = {
     "lkgd_timestep_embedding": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp]),
     "lkgd_silu": (_i32, [_vp, _vp, _i64, _vp]),
     "lkgd_add": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "lkgd_scale": (_i32, [_vp, _vp, _i64, _f32, _vp]),
+    "lkgd_euler_step": (_i32, [_vp, _vp, _i32, _vp, _i64, _f32, _f32, _i32, _vp]),
     "lkgd_version": (C.c_char_p, []),
 }
 

@@ -128,6 +128,28 @@ __global__ __launch_bounds__(256) void add_kernel(const half_t* __restrict__ a, 
   }
 }
 
+// ---- standalone scheduler API kernels (scale_model_input :264-288 / step :418-528 on tensors of any shape)
+__global__ __launch_bounds__(256) void scale_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, long long n,
+                                                    float s) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    y[i] = (half_t)((float)x[i] * s);
+}
+template <typename ST>
+__global__ __launch_bounds__(256) void euler_kernel(const half_t* __restrict__ mo, const ST* __restrict__ sample,
+                                                    half_t* __restrict__ prev, long long n, float sigma,
+                                                    float sigma_next, int vpred) {
+  const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f);
+  const float c_skip = sigma * sigma + 1.0f;
+  const float dt = sigma_next - sigma;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float x = (float)sample[i];
+    float x0;
+    if (vpred) x0 = (float)(half_t)((float)mo[i] * c_out) + x / c_skip;
+    else x0 = x - (float)(half_t)((float)mo[i] * sigma);
+    prev[i] = (half_t)(x + (x - x0) / sigma * dt);
+  }
+}
+
 static unsigned grid_for(long long work_items, int per_block) {
   long long g = (work_items + per_block - 1) / per_block;
   if (g > 256 * 16) g = 256 * 16;
@@ -216,6 +238,31 @@ extern "C" int lkgd_add(const void* a, const void* b, void* y, int64_t n, lkgd_s
   if (!aligned16(a) || !aligned16(b) || !aligned16(y)) return LKGD_E_ALIGN;
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, (const half_t*)a,
                      (const half_t*)b, (half_t*)y, (long long)n);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+extern "C" int lkgd_scale(const void* x, void* y, int64_t n, float s, lkgd_stream_t stream) {
+  if (!x || !y) return LKGD_E_NULL;
+  if (n <= 0) return LKGD_E_SHAPE;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                     (half_t*)y, (long long)n, s);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+extern "C" int lkgd_euler_step(const void* model_output, const void* sample, int32_t sample_is_f32, void* prev,
+                               int64_t n, float sigma, float sigma_next, int32_t prediction_type,
+                               lkgd_stream_t stream) {
+  if (!model_output || !sample || !prev) return LKGD_E_NULL;
+  if (n <= 0 || !(sigma > 0.f)) return LKGD_E_SHAPE;
+  if (prediction_type != 0 && prediction_type != 1) return LKGD_E_MODE;
+  if (sample_is_f32)
+    hipLaunchKernelGGL(euler_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)model_output, (const float*)sample, (half_t*)prev, (long long)n, sigma,
+                       sigma_next, prediction_type);
+  else
+    hipLaunchKernelGGL(euler_kernel<half_t>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)model_output, (const half_t*)sample, (half_t*)prev, (long long)n, sigma,
+                       sigma_next, prediction_type);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 

@@ -1,0 +1,103 @@
+"""Frame-parallel sharding of one clip over the GPUs of a node (one process per GPU, RCCL over xGMI).
+
+There is no counterpart in the reference (its SVD path is single-GPU); the scheme is the one
+BASELINE.json's north_star names and SURVEY.md 8e details:
+
+* ranks = cfg_groups x frame_shards.  With classifier-free guidance the two CFG halves (uncond / cond) are independent
+  through the whole UNet, so the first factor of 2 is CFG-parallel and costs ONE tiny exchange per step (the CFG combine);
+* inside a CFG half the F frames are split into contiguous slices (14 frames over 4 shards = 4,4,3,3).  All spatial work
+  (2-D convs, spatial attention, feed-forwards, per-frame GroupNorm) is local.  Temporal ops couple frames at a pixel:
+  - temporal GroupNorm: all-reduce of the [32,2] fp32 partial sums (not the activations),
+  - temporal Conv3d (3,1,1) and temporal attention K/V: all-gather of the frame slices (padded to equal size, because
+    RCCL's all-gather wants equal counts) right before the op.
+
+This module is the HOST logic of that scheme: the shard plan and the padded gather.  It is pure torch.distributed
+(backend "nccl" == RCCL on the GPU box, "gloo" in the CPU tests), no kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class ShardPlan:
+    world: int
+    rank: int
+    cfg_groups: int            # 1 or 2
+    frame_shards: int
+    cfg_index: int             # which CFG half this rank computes (0 = uncond, 1 = cond); 0 when cfg_groups == 1
+    shard_index: int
+    splits: Tuple[int, ...]    # frames per shard
+    f0: int                    # first frame of this rank
+    num_frames: int
+
+    @property
+    def f_local(self) -> int:
+        return self.splits[self.shard_index]
+
+    @property
+    def f_max(self) -> int:
+        return max(self.splits)
+
+    def frame_group_ranks(self) -> List[int]:
+        """ranks that hold the other frame slices of the same CFG half"""
+        base = self.cfg_index * self.frame_shards
+        return list(range(base, base + self.frame_shards))
+
+    def cfg_partner_ranks(self) -> List[int]:
+        """ranks that hold the same frame slice of each CFG half"""
+        return [c * self.frame_shards + self.shard_index for c in range(self.cfg_groups)]
+
+
+def split_frames(num_frames: int, shards: int) -> Tuple[int, ...]:
+    """contiguous, as even as possible, larger slices first: 14 over 4 -> (4, 4, 3, 3)"""
+    if shards < 1 or shards > num_frames:
+        raise ValueError(f"cannot split {num_frames} frames over {shards} shards")
+    q, r = divmod(num_frames, shards)
+    return tuple(q + 1 if i < r else q for i in range(shards))
+
+
+def make_plan(world: int, rank: int, num_frames: int, cfg: bool) -> ShardPlan:
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    cfg_groups = 2 if (cfg and world >= 2) else 1
+    if world % cfg_groups:
+        raise ValueError(f"world size {world} must be even when classifier-free guidance is on")
+    shards = world // cfg_groups
+    splits = split_frames(num_frames, shards)
+    ci, si = divmod(rank, shards)
+    return ShardPlan(world, rank, cfg_groups, shards, ci, si, splits, sum(splits[:si]), num_frames)
+
+
+def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+    """local [f_local, ...] -> [num_frames, ...] over the frame group (padded equal-count all-gather + compaction)."""
+    if plan.frame_shards == 1:
+        return local
+    fmax = plan.f_max
+    if local.shape[0] != plan.f_local:
+        raise ValueError("local frame count does not match the plan")
+    send = local
+    if plan.f_local < fmax:
+        send = torch.zeros((fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[:plan.f_local].copy_(local)
+    buf = torch.empty((plan.frame_shards * fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
+    if all(s == fmax for s in plan.splits):
+        return buf
+    out = torch.empty((plan.num_frames,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    f = 0
+    for j, n in enumerate(plan.splits):
+        out[f:f + n].copy_(buf[j * fmax:j * fmax + n])
+        f += n
+    return out
+
+
+def allreduce_sums(sums: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+    """sum of the GroupNorm partial sums over the frame group (fp32, a few hundred bytes)"""
+    if plan.frame_shards > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums

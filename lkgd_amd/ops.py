@@ -15,6 +15,10 @@ A_PLAIN, A_CONV3X3, A_TCONV3, A_CONV3X3_C8 = 0, 1, 2, 3
 
 _zeros = {}
 
+#: when a list, every GEMM launch is bracketed by HIP events on the launch stream and (start, end, algorithmic_flop)
+#: is appended (bench.py's live roofline measurement); None = off
+GEMM_EVENTS = None
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -98,6 +102,14 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     d.ldc = _ld(out)
     d.s_acc, d.r1, d.r2 = s_acc, r1, r2
     d.geglu = 1 if geglu else 0
+    ev = GEMM_EVENTS
+    if ev is not None:
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+        check(_lib.lib().lkgd_gemm_f16(C.byref(d), _stream()), "lkgd_gemm_f16")
+        e_ev.record()
+        ev.append((s_ev, e_ev, 2.0 * M * N * (72 if mode == A_CONV3X3_C8 else K)))
+        return out
     check(_lib.lib().lkgd_gemm_f16(C.byref(d), _stream()), "lkgd_gemm_f16")
     return out
 
@@ -235,3 +247,24 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(a)
     check(_lib.lib().lkgd_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "lkgd_add")
     return y
+
+
+def scale(x: torch.Tensor, s: float) -> torch.Tensor:
+    _req(x, torch.float16, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().lkgd_scale(x.data_ptr(), y.data_ptr(), x.numel(), s, _stream()), "lkgd_scale")
+    return y
+
+
+def euler_step(model_output: torch.Tensor, sample: torch.Tensor, sigma: float, sigma_next: float,
+               v_prediction: bool = True) -> torch.Tensor:
+    _req(model_output, torch.float16, "model_output")
+    if not sample.is_cuda or sample.dtype not in (torch.float16, torch.float32):
+        raise _lib.LkgdHipError("sample must be a GPU fp16/fp32 tensor")
+    mo, sm = model_output.contiguous(), sample.contiguous()
+    prev = torch.empty_like(mo)
+    check(_lib.lib().lkgd_euler_step(mo.data_ptr(), sm.data_ptr(), int(sm.dtype == torch.float32), prev.data_ptr(),
+                                     mo.numel(), sigma, sigma_next, 1 if v_prediction else 0, _stream()),
+          "lkgd_euler_step")
+    return prev

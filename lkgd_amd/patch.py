@@ -1,0 +1,141 @@
+"""The reference's ``patch`` API on the lkgd_amd UNet (joint attention ``attn1n`` between paired batch entries).
+
+Mirrors /root/reference/patch/patch.py: ``apply_patch`` :719-817, ``remove_patch`` :820-838, ``update_patch`` :841-853,
+``collect_from_patch`` :856-870, ``set_joint_attention`` :938-950, ``set_joint_scale`` :952-963,
+``initialize_joint_layers`` :966-977 (block side :143-172), ``set_joint_attention_mask`` :985-996.
+
+The reference swaps ``module.__class__`` to a ToMeBlock whose Python ``forward`` does the extra attention in eager
+PyTorch.  Here the blocks already own the joint branch as HIP kernel launches (lkgd_amd/unet.py
+``BasicTransformerBlock._joint`` / ``TemporalBasicTransformerBlock._joint``: the spatial flash-attention /
+temporal-attention kernels with a K/V batch permutation + the zero-init ``conv1n`` projection as a GEMM epilogue), so
+"patching" marks which blocks take part and carries the flags.  Blocks are found the way the reference finds them: by
+class NAME in the MRO (patch/utils.py:4-16).  The boolean-mask partner selection (:466-468) becomes a static int32
+permutation computed on the host from the 4-entry mask (masks are constants, utils/util.py:600-606).
+
+LoRA-mask plumbing (``set_patch_lora_mask`` / ``hack_lora_forward`` / ``initialize_joint_lora`` :57-92,:872-936) targets
+peft-wrapped Linear layers during training; inference merges LoRA into the base weights, so these
+entry points exist and raise with that explanation rather than silently doing nothing.
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+import torch.nn as nn
+
+from ._lib import LkgdHipError
+
+
+def isinstance_str(x: object, cls_name: str) -> bool:
+    return any(c.__name__ == cls_name for c in x.__class__.__mro__)
+
+
+def _model(model):
+    return model.unet if hasattr(model, "unet") else model
+
+
+def _patched_blocks(model):
+    for name, m in _model(model).named_modules():
+        if getattr(m, "_lkgd_patched", False):
+            yield name, m
+
+
+def apply_patch(model, seed: int = 123, flip=False, with_spatial_block=True, with_temporal_block=False,
+                single_dir=False, name_skip=None):
+    remove_patch(model)
+    dm = _model(model)
+    dm._tome_info = {"size": None, "hooks": [],
+                     "args": {"generator": None, "seed": seed, "flip": flip, "single_dir": single_dir}}
+    for name, m in dm.named_modules():
+        if name_skip is not None and name_skip in name:
+            continue
+        is_s = isinstance_str(m, "BasicTransformerBlock")
+        is_t = isinstance_str(m, "TemporalBasicTransformerBlock")
+        if (with_spatial_block and is_s) or (with_temporal_block and is_t):
+            m._lkgd_patched = True
+            m._tome_info = dm._tome_info
+            m.enable_joint_attention = True      # class-level default of the reference's ToMeBlock (:104)
+            m.joint_scale = 1.0
+    return model
+
+
+def remove_patch(model):
+    dm = _model(model)
+    for _, m in dm.named_modules():
+        if getattr(m, "_lkgd_patched", False):
+            m._lkgd_patched = False
+            m.enable_joint_attention = False
+    if hasattr(dm, "_tome_info"):
+        del dm._tome_info
+    return model
+
+
+def update_patch(model, **kwargs):
+    for _, m in _model(model).named_modules():
+        if hasattr(m, "_tome_info"):
+            for k, v in kwargs.items():
+                setattr(m, k, v)
+    return model
+
+
+def collect_from_patch(model, attr="tome"):
+    return {n: getattr(m, attr) for n, m in _model(model).named_modules() if hasattr(m, attr)}
+
+
+def initialize_joint_layers(model, post="conv", add_norm=False):
+    if add_norm:
+        raise LkgdHipError("add_norm=True (AdaLayerNormContinuous norm1n) is not used by the SVD configs")
+    dm = _model(model)
+    for _, m in _patched_blocks(model):
+        m.attn1n = copy.deepcopy(m.attn1)
+        dim = m.attn1n.out_dim
+        dev, dt = m.attn1.to_q.weight.device, m.attn1.to_q.weight.dtype
+        if post == "conv":
+            m.conv1n = nn.Linear(dim, dim, bias=False, device=dev, dtype=dt)
+            nn.init.zeros_(m.conv1n.weight)
+        elif post in ("scale", "conv_fuse"):
+            raise LkgdHipError(f"post='{post}' is not implemented on the HIP path (the SVD loaders use 'conv', "
+                               "utils/util.py:562)")
+        else:
+            raise AssertionError(f"Unkown post processing type {post}")
+        m.add_norm = False
+        m.post = post
+        m.joint_scale = 1.0
+    dm.invalidate()
+    return model
+
+
+def set_joint_attention(model, enable=True, name_filter=None):
+    for name, m in _patched_blocks(model):
+        if name_filter is None or name_filter in name:
+            m.enable_joint_attention = enable
+    return model
+
+
+def set_joint_scale(model, scale=1.0):
+    for _, m in _patched_blocks(model):
+        m.joint_scale = scale
+    return model
+
+
+def set_joint_attention_mask(model, joint_attn_mask):
+    dm = _model(model)
+    mask = torch.tensor(joint_attn_mask, dtype=torch.bool)
+    dm._joint_attn_mask = mask
+    for _, m in _patched_blocks(model):
+        m.joint_attn_mask = mask
+    return model
+
+
+def _training_only(name):
+    def f(*a, **k):
+        raise LkgdHipError(f"patch.{name} manipulates peft LoRA layers at training time; the MI355X inference path "
+                           "expects LoRA merged into the base weights (W += B@A*scale) before load_state_dict")
+    f.__name__ = name
+    return f
+
+
+set_patch_lora_mask = _training_only("set_patch_lora_mask")
+hack_lora_forward = _training_only("hack_lora_forward")
+initialize_joint_lora = _training_only("initialize_joint_lora")
+set_joint_layer_requires_grad = _training_only("set_joint_layer_requires_grad")

@@ -1,0 +1,249 @@
+"""StableVideoDiffusionPipeline with the reference's ``__call__`` signature; the denoising loop runs on the HIP path.
+
+Mirrors /root/reference/pipeline/pipeline_stable_video_diffusion_trans.py: ``__call__`` :352-656 (signature :352-372,
+loop :545-640), ``_encode_image`` :157-203, ``_encode_vae_image`` :205-226, ``_get_add_time_ids`` :228-254,
+``decode_latents`` :256-283, ``prepare_latents`` :299-331, ``check_inputs`` :285-297.
+
+Scope: the hot path is the loop body.  ``denoise()`` is that loop: per step ONE glue kernel
+(CFG duplicate + scale_model_input + channel concat -> channels-last tokens), the UNet forward on tokens, ONE glue
+kernel (per-frame CFG + v-prediction + Euler update).  No host<->device sync inside the loop (sigma tables live on the
+host).  CLIP / VAE are boundary stages: any modules with the diffusers interface may be passed in and are called as the
+reference calls them; they are not re-implemented here (8f rank 2).
+The LKGD conditioning (domain / flow ViT logits) is passed as ``domain_features`` / ``flow_features`` (intended wiring:
+CogVideo-main/finetune/models/cogvideox_i2v/pipeline_cogvideox_image2video.py:794-799,849-859) and fused ONCE per clip.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Union
+
+import torch
+
+from . import ops
+from ._lib import LkgdHipError
+from .scheduler import EulerDiscreteScheduler
+
+
+@dataclass
+class StableVideoDiffusionPipelineOutput:
+    frames: Union[torch.Tensor, list]
+
+
+def _append_dims(x, target_dims):
+    dims_to_append = target_dims - x.ndim
+    if dims_to_append < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {target_dims}, which is less")
+    return x[(...,) + (None,) * dims_to_append]
+
+
+class StableVideoDiffusionPipeline:
+    model_cpu_offload_seq = "image_encoder->unet->vae"
+    _callback_tensor_inputs = ["latents"]
+
+    def __init__(self, vae=None, image_encoder=None, unet=None, scheduler: Optional[EulerDiscreteScheduler] = None,
+                 feature_extractor=None):
+        self.vae, self.image_encoder, self.unet = vae, image_encoder, unet
+        self.scheduler = scheduler if scheduler is not None else EulerDiscreteScheduler.from_svd_config()
+        self.feature_extractor = feature_extractor
+        self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
+        self._guidance_scale = None
+        self._num_timesteps = 0
+
+    # ---- reference helpers -------------------------------------------------------------------------------------
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        if isinstance(self.guidance_scale, (int, float)):
+            return self.guidance_scale > 1
+        return self.guidance_scale.max() > 1
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    @property
+    def _execution_device(self):
+        return self.unet.device
+
+    def enable_model_cpu_offload(self, *a, **k):
+        return None   # a memory knob of the reference (run_inference_svd.py:171); nothing to offload at 288 GB
+
+    def check_inputs(self, image, height, width):
+        import PIL.Image
+        if not isinstance(image, (torch.Tensor, PIL.Image.Image, list)):
+            raise ValueError("`image` has to be of type `torch.FloatTensor` or `PIL.Image.Image` or "
+                             f"`List[PIL.Image.Image]` but is {type(image)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+
+    def _get_add_time_ids(self, fps, motion_bucket_id, noise_aug_strength, dtype, batch_size, num_videos_per_prompt,
+                          do_classifier_free_guidance):
+        add_time_ids = [fps, motion_bucket_id, noise_aug_strength]
+        passed = self.unet.config.addition_time_embed_dim * len(add_time_ids)
+        expected = self.unet.add_embedding.linear_1.in_features
+        if expected != passed:
+            raise ValueError(f"Model expects an added time embedding vector of length {expected}, but a vector of "
+                             f"{passed} was created. The model has an incorrect config.")
+        ids = torch.tensor([add_time_ids], dtype=dtype).repeat(batch_size * num_videos_per_prompt, 1)
+        if do_classifier_free_guidance:
+            ids = torch.cat([ids, ids])
+        return ids
+
+    def prepare_latents(self, batch_size, num_frames, num_channels_latents, height, width, dtype, device, generator,
+                        latents=None):
+        shape = (batch_size, num_frames, num_channels_latents // 2, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}.")
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else device
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device=device, dtype=dtype)
+        return ops.scale(latents, float(self.scheduler.init_noise_sigma))
+
+    def _encode_image(self, image, device, num_videos_per_prompt, do_classifier_free_guidance):
+        """boundary stage (CLIP), reference :157-203; tensor input only (the PIL resize path is 8f rank 2)"""
+        if self.image_encoder is None:
+            raise LkgdHipError("no image_encoder given: pass `image_embeddings=` to __call__ or call denoise()")
+        if not isinstance(image, torch.Tensor):
+            raise NotImplementedError("PIL input needs the CLIP preprocessing boundary stage (SURVEY.md 8f rank 2); "
+                                      "pass a [B,3,224,224] tensor in [0,1] or precomputed image_embeddings")
+        dtype = next(self.image_encoder.parameters()).dtype
+        image = self.feature_extractor(images=image, do_normalize=True, do_center_crop=False, do_resize=False,
+                                       do_rescale=False, return_tensors="pt").pixel_values
+        emb = self.image_encoder(image.to(device=device, dtype=dtype)).image_embeds.unsqueeze(1)
+        bs, seq, _ = emb.shape
+        emb = emb.repeat(1, num_videos_per_prompt, 1).view(bs * num_videos_per_prompt, seq, -1)
+        if do_classifier_free_guidance:
+            emb = torch.cat([torch.zeros_like(emb), emb])
+        return emb
+
+    def _encode_vae_image(self, image, device, num_videos_per_prompt, do_classifier_free_guidance):
+        if self.vae is None:
+            raise LkgdHipError("no vae given: pass `image_latents=` to __call__ or call denoise()")
+        lat = self.vae.encode(image.to(device=device)).latent_dist.mode()
+        if do_classifier_free_guidance:
+            lat = torch.cat([torch.zeros_like(lat), lat])
+        return lat.repeat(num_videos_per_prompt, 1, 1, 1)
+
+    def decode_latents(self, latents, num_frames, decode_chunk_size=14):
+        if self.vae is None:
+            raise LkgdHipError("no vae given: use output_type='latent'")
+        latents = latents.flatten(0, 1)
+        latents = 1 / self.vae.config.scaling_factor * latents
+        frames = []
+        for i in range(0, latents.shape[0], decode_chunk_size):
+            n_in = latents[i:i + decode_chunk_size].shape[0]
+            frames.append(self.vae.decode(latents[i:i + decode_chunk_size], num_frames=n_in).sample)
+        frames = torch.cat(frames, dim=0)
+        frames = frames.reshape(-1, num_frames, *frames.shape[1:]).permute(0, 2, 1, 3, 4)
+        return frames.float()
+
+    # ---- the hot path ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, image_embeddings: torch.Tensor,
+                added_time_ids: torch.Tensor, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
+                max_guidance_scale: float = 3.0, domain_features: Optional[torch.Tensor] = None,
+                flow_features: Optional[torch.Tensor] = None, callback_on_step_end: Optional[Callable] = None,
+                callback_on_step_end_tensor_inputs: List[str] = ["latents"]) -> torch.Tensor:
+        """Reference loop :503-640.  ``latents`` [B,F,4,h,w] already scaled by init_noise_sigma (fp16 or fp32, updated
+        in place and returned); ``image_latents`` [cfg*B,F,4,h,w] fp16; ``image_embeddings`` [cfg*B,1,1024]."""
+        unet, sch = self.unet, self.scheduler
+        dev = unet.device
+        B, F, _, H, W = latents.shape
+        cfg = 2 if max_guidance_scale > 1 else 1
+        if image_latents.shape[0] != cfg * B or image_embeddings.shape[0] != cfg * B:
+            raise ValueError("image_latents / image_embeddings must carry cfg*batch entries (uncond first)")
+        latents = latents.to(dev).contiguous()
+        image_latents = image_latents.to(device=dev, dtype=torch.float16).contiguous()
+        sch.set_timesteps(num_inference_steps, device=None)
+        self._num_timesteps = len(sch.timesteps_host)
+        guidance = torch.linspace(min_guidance_scale, max_guidance_scale, F, dtype=torch.float32)
+        self._guidance_scale = _append_dims(guidance.unsqueeze(0).repeat(B, 1), latents.ndim)
+        guidance_dev = guidance.to(dev)
+        enc = image_embeddings.to(dev)
+        if domain_features is not None:
+            if not hasattr(unet, "fused_embedding"):
+                raise LkgdHipError("domain/flow features need the LKGD UNet (UNetSpatioTemporalConditionModel)")
+            enc = unet.fused_embedding(enc, domain_features.to(dev), flow_features.to(dev))   # once per clip
+        ids = added_time_ids.to(dev)
+        vpred = sch.config.prediction_type == "v_prediction"
+        from . import patch as _patch
+        for i, t in enumerate(sch.timesteps_host):
+            sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
+            tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)
+            _patch.set_joint_attention(unet, enable=True)       # reference :555 (no-op unless the model is patched)
+            noise_tok, _ = unet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids)
+            ops.cfg_euler_step(noise_tok, latents, guidance_dev, cfg, sigma, sigma_next, v_prediction=vpred)
+            if callback_on_step_end is not None:
+                kw = {k: {"latents": latents}[k] for k in callback_on_step_end_tensor_inputs}
+                out = callback_on_step_end(self, i, t, kw)
+                latents = out.pop("latents", latents) if isinstance(out, dict) else latents
+        sch._step_index = num_inference_steps
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, image, height: int = 576, width: int = 1024, num_frames: Optional[int] = None,
+                 num_inference_steps: int = 25, min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0,
+                 fps: int = 7, motion_bucket_id: int = 127, noise_aug_strength: float = 0.02,
+                 decode_chunk_size: Optional[int] = None, num_videos_per_prompt: Optional[int] = 1,
+                 generator=None, latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "pil",
+                 callback_on_step_end: Optional[Callable[[int, int, Dict], None]] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], return_dict: bool = True,
+                 # extensions (keyword-only in practice; defaults keep the reference call sites unchanged)
+                 image_embeddings: Optional[torch.Tensor] = None, image_latents: Optional[torch.Tensor] = None,
+                 domain_features: Optional[torch.Tensor] = None, flow_features: Optional[torch.Tensor] = None):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
+        decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames
+        if image is not None:
+            self.check_inputs(image, height, width)
+        if isinstance(image, torch.Tensor):
+            batch_size = image.shape[0]
+        elif isinstance(image, list):
+            batch_size = len(image)
+        elif image is None:
+            batch_size = image_latents.shape[0] // (2 if max_guidance_scale > 1 else 1)
+        else:
+            batch_size = 1
+        device = self._execution_device
+        self._guidance_scale = max_guidance_scale
+        cfg = self.do_classifier_free_guidance
+        if image_embeddings is None:
+            image_embeddings = self._encode_image(image, device, num_videos_per_prompt, cfg)
+        fps = fps - 1
+        if image_latents is None:
+            if not isinstance(image, torch.Tensor):
+                raise NotImplementedError("PIL input needs the VaeImageProcessor boundary stage (SURVEY.md 8f rank 2)")
+            img = (2.0 * image - 1.0).to(device)
+            noise = torch.randn(img.shape, generator=generator, device=img.device, dtype=img.dtype)
+            img = img + noise_aug_strength * noise
+            image_latents = self._encode_vae_image(img, device, num_videos_per_prompt, cfg)
+        image_latents = image_latents.to(device=device, dtype=torch.float16)
+        if image_latents.dim() == 4:      # [cfg*B,4,h,w] -> repeat over frames (:488)
+            image_latents = image_latents.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)
+        added_time_ids = self._get_add_time_ids(fps, motion_bucket_id, noise_aug_strength, torch.float32, batch_size,
+                                                num_videos_per_prompt, cfg).to(device)
+        self.scheduler.set_timesteps(num_inference_steps, device=None)
+        lat = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, self.unet.config.in_channels,
+                                   height, width, torch.float16, device, generator, latents)
+        lat = self.denoise(lat, image_latents.contiguous(), image_embeddings, added_time_ids, num_inference_steps,
+                           min_guidance_scale, max_guidance_scale, domain_features, flow_features,
+                           callback_on_step_end, callback_on_step_end_tensor_inputs)
+        if output_type != "latent":
+            frames = self.decode_latents(lat, num_frames, decode_chunk_size)
+            if output_type == "pt":
+                pass
+            else:
+                raise NotImplementedError("output_type 'pil'/'np' needs the VaeImageProcessor boundary stage")
+        else:
+            frames = lat
+        if not return_dict:
+            return frames
+        return StableVideoDiffusionPipelineOutput(frames=frames)

@@ -311,7 +311,9 @@ class TemporalBasicTransformerBlock(nn.Module):
         att = ctx.new(T, Cc)
         ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
                           self.attn1.heads)
-        if order == "interleaved_0_27":
+        if isinstance(order, tuple):
+            xmap = order                      # explicit context-row map (tests drive single blocks this way)
+        elif order == "interleaved_0_27":
             xmap = (ctx.F * ctx.HW, ctx.HW, ctx.HW, ctx.B)
         elif order == "batch_major":
             xmap = ops.rowmap_div(ctx.F * ctx.HW)

@@ -1,0 +1,147 @@
+"""CPU-side checks of the product's host logic (no kernels run): the C-ABI library loads and exports every symbol the
+header declares, the scheduler host tables equal the reference's KAT, state-dict compatibility with the diffusers
+names, weight packing layouts, patch API bookkeeping, loud failure without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lkgd_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "lkgd_hip.h")).read()
+    declared = set(re.findall(r"\b(lkgd_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("lkgd_gemm_desc")
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.lib()                       # loads liblkgd_hip.so (links libamdhip64; no GPU needed to load)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.lkgd_version().decode().startswith("lkgd_hip")
+    assert ctypes.sizeof(_lib.GemmDesc) == 9 * 8 + 28 * 4
+
+
+def test_gemm_desc_validation_without_gpu():
+    """argument errors are reported before anything touches the device"""
+    from lkgd_amd import _lib
+    d = _lib.GemmDesc()
+    assert _lib.lib().lkgd_gemm_f16(ctypes.byref(d), None) == -1      # LKGD_E_NULL
+    assert _lib.lib().lkgd_groupnorm_chunks(129, 320) == 3
+
+
+def test_scheduler_tables_equal_reference_kat():
+    from lkgd_amd.scheduler import EulerDiscreteScheduler
+    with open(os.path.join(REPO, "tests", "golden", "scheduler_kat.json")) as f:
+        kat = json.load(f)
+    for c in kat["cases"]:
+        s = EulerDiscreteScheduler(**kat["config"])
+        s.set_timesteps(c["n"])
+        assert torch.equal(s.sigmas, torch.tensor(c["sigmas"]))
+        assert torch.equal(s.timesteps, torch.tensor(c["timesteps"]))
+        assert float(s.init_noise_sigma) == c["init_noise_sigma"]
+        assert s.order == 1 and s.step_index is None
+    s = EulerDiscreteScheduler.from_svd_config()
+    s.set_timesteps(25)
+    with pytest.raises(ValueError):
+        s.step(torch.zeros(1), 3, torch.zeros(1))          # integer timestep guard (:458-469)
+
+
+def test_state_dict_names_match_diffusers_tree():
+    from lkgd_amd import unet as pu
+    from oracle import unet as ou
+    for ocls, pcls in ((ou.UNetSpatioTemporalConditionControlNetModel, pu.UNetSpatioTemporalConditionControlNetModel),
+                       (ou.UNetSpatioTemporalConditionModel, pu.UNetSpatioTemporalConditionModel)):
+        with torch.device("meta"):
+            o, p = ocls(ou.SVD_CONFIG), pcls(pu.UNetConfig())
+        so, sp = o.state_dict(), p.state_dict()
+        assert set(so) == set(sp)
+        assert all(so[k].shape == sp[k].shape for k in so)
+    assert sum(v.numel() for v in sp.values()) == 1_524_623_082 + 726_796
+    names = {type(m).__name__ for m in p.modules()}
+    assert {"BasicTransformerBlock", "TemporalBasicTransformerBlock"} <= names   # what patch looks for
+    assert p.config.in_channels == 8 and p.config.num_frames == 14 and p.add_embedding.linear_1.in_features == 768
+    blk = p.down_blocks[0].attentions[0].transformer_blocks[0]
+    for a in ("attn1", "attn2", "norm1", "norm2", "norm3", "ff", "norm_type", "pos_embed", "only_cross_attention",
+              "_chunk_size", "_chunk_dim"):
+        assert hasattr(blk, a), a
+    assert blk.attn1.out_dim == 320
+
+
+def test_packing_layouts():
+    from lkgd_amd import packing as pk
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(6, 4, 3, 3, generator=g)
+    p = pk.pack_conv3x3(w)
+    assert p.shape == (6, 36) and p.dtype == torch.float16
+    assert torch.equal(p[2, (1 * 3 + 2) * 4 + 3], w[2, 3, 1, 2].half())
+    w8 = torch.randn(5, 8, 3, 3, generator=g)
+    p = pk.pack_conv3x3_c8(w8)
+    assert p.shape == (5, 128) and torch.equal(p[:, 72:], torch.zeros(5, 56, dtype=torch.float16))
+    assert torch.equal(p[1, 4 * 8 + 7], w8[1, 7, 1, 1].half())
+    wt = torch.randn(6, 4, 3, 1, 1, generator=g)
+    p = pk.pack_tconv3(wt)
+    assert torch.equal(p[3, 2 * 4 + 1], wt[3, 1, 2, 0, 0].half())
+    perm = pk.geglu_perm(128)
+    assert perm[:64].tolist() == list(range(64)) and perm[64:128].tolist() == list(range(128, 192))
+    assert perm[128:192].tolist() == list(range(64, 128)) and sorted(perm.tolist()) == list(range(256))
+
+
+def test_patch_api_bookkeeping():
+    from lkgd_amd import patch
+    from lkgd_amd import unet as pu
+    from oracle import unet as ou
+    m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    patch.apply_patch(m, flip=True, with_spatial_block=True, with_temporal_block=False)
+    sp = [b for b in m.modules() if type(b).__name__ == "BasicTransformerBlock"]
+    tp = [b for b in m.modules() if type(b).__name__ == "TemporalBasicTransformerBlock"]
+    assert all(b.enable_joint_attention for b in sp) and not any(b.enable_joint_attention for b in tp)
+    assert m._tome_info["args"]["flip"] is True
+    patch.initialize_joint_layers(m)
+    assert all(hasattr(b, "attn1n") and float(b.conv1n.weight.abs().sum()) == 0.0 for b in sp)
+    assert any(k.endswith("attn1n.to_q.weight") for k in m.state_dict())      # A.10 hook names
+    patch.set_joint_attention_mask(m, [0, 1, 0, 1])
+    patch.set_joint_scale(m, 0.25)
+    assert all(b.joint_scale == 0.25 for b in sp)
+    patch.set_joint_attention(m, False, name_filter="down_blocks")
+    assert not m.down_blocks[0].attentions[0].transformer_blocks[0].enable_joint_attention
+    assert m.mid_block.attentions[0].transformer_blocks[0].enable_joint_attention
+    patch.update_patch(m, foo=3)
+    assert patch.collect_from_patch(m, "foo")
+    patch.remove_patch(m)
+    assert not any(b.enable_joint_attention for b in sp)
+    # partner permutation for masks [0,1,0,1], B=4, F=3 (patch.py:466-475)
+    patch.apply_patch(m, flip=False)
+    patch.set_joint_attention_mask(m, [0, 1, 0, 1])
+    ctx = pu.Ctx(4, 3, 2, 2, torch.device("cpu"))
+    m._joint_maps(ctx)
+    assert ctx.spatial_partner.tolist() == [3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8]
+    assert ctx.temporal_partner.tolist() == [1, 0, 3, 2]
+    m._tome_info["args"]["flip"] = True
+    m._joint_maps(ctx)
+    assert ctx.spatial_partner.tolist() == [5, 4, 3, 2, 1, 0, 11, 10, 9, 8, 7, 6]
+    with pytest.raises(Exception):
+        patch.hack_lora_forward(m)
+
+
+def test_forward_fails_loudly_without_gpu():
+    from lkgd_amd import LkgdHipError
+    from lkgd_amd import unet as pu
+    from oracle import unet as ou
+    m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    with pytest.raises(LkgdHipError):
+        m(torch.zeros(1, 2, 8, 8, 8), 1.0, torch.zeros(1, 1, 1024), added_time_ids=torch.zeros(1, 3))
+    with pytest.raises(LkgdHipError):
+        pu.Attention(64, None, 4, 16)          # head_dim != 64 is refused at construction
+
+
+def test_product_does_not_import_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import lkgd_amd, lkgd_amd.unet, lkgd_amd.pipeline, lkgd_amd.patch, "
+            "lkgd_amd.scheduler, lkgd_amd.lk_fuse, lkgd_amd.dist; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % REPO)
+    subprocess.run([sys.executable, "-c", code], check=True)
