@@ -39,7 +39,7 @@ enum {
  *
  *    out[m, n] = s_acc * ( sum_k A(m,k) * W[n,k] + bias[n] + rowbias[idx(m), n] )
  *                + r1 * res1[m, n] + r2 * res2[m, n]                           (fp32 accumulate, fp16 store)
- *    with idx(m) = ((m / rb_d1) * rb_m1 + (m % rb_d2)) % rb_md
+ *    with idx(m) = ((m / rb_d1) * rb_m1 + (m % rb_d2) + rb_c0) % rb_md
  *    GEGLU (geglu=1): W rows are tile-interleaved [64 hidden | 64 gate]; out[m, j] = hidden * gelu_erf(gate),
  *                     out has N/2 columns.
  *
@@ -48,7 +48,8 @@ enum {
  *      LKGD_A_CONV3X3   k = (ky*3+kx)*Cin + c; token m = (n, y, x) on the Hout x Wout grid reads source pixel
  *                       ((y*stride+ky-1) >> ups, (x*stride+kx-1) >> ups) of the Hin x Win grid, zero outside
  *                       (pad 1); ups=1 folds nearest-2x upsampling into the gather; channel c from a0 / a1 as above
- *      LKGD_A_TCONV3    k = kt*Cin + c; token m = (b, f, s) reads frame f+kt-1 (zero outside [0,F)); Conv3d (3,1,1)
+ *      LKGD_A_TCONV3    k = kt*Cin + c; token m = (b, f, s) reads frame f+kt-1 (zero outside [0,F)); Conv3d (3,1,1);
+ *                       m = (b*Floc + fl)*HW + s is output frame f = f_off + fl, source row (b*F + f+kt-1)*HW + s
  *      LKGD_A_CONV3X3_C8 conv3x3 with Cin == 8 (conv_in): one 16-byte chunk per tap, K padded to 128
  *
  *    Replaces (reference call sites):
@@ -78,8 +79,10 @@ typedef struct lkgd_gemm_desc {
   int32_t lda0, lda1, csplit;
   int32_t mode, Cin;
   int32_t Hout, Wout, Hin, Win, stride, ups;
-  int32_t F, HW;
-  int32_t ldrb, rb_d1, rb_m1, rb_d2, rb_md;
+  int32_t F, HW;           /* TCONV3: frames per batch entry in the SOURCE tensor, tokens per frame */
+  int32_t Floc, f_off;     /* TCONV3 under frame sharding: output rows cover Floc frames per batch entry starting at
+                              global frame f_off; the source a0 holds all F frames.  Unsharded: Floc = F, f_off = 0 */
+  int32_t ldrb, rb_d1, rb_m1, rb_d2, rb_md, rb_c0;
   int32_t ldr1, ldr2, ldc;
   float s_acc, r1, r2;
   int32_t geglu;
@@ -100,6 +103,12 @@ int lkgd_groupnorm_chunks(int64_t rows_per_sample, int32_t C);
 int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
                          int64_t nsamples, int64_t rows_per_sample, float eps, float* partial, float* stats,
                          lkgd_stream_t stream);
+/* frame-sharded variant: raw per-(sample, group) fp32 (sum, sum of squares) of the LOCAL rows - all-reduced across the
+ * frame group by the host (RCCL) - then finalised with the GLOBAL element count per group */
+int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
+                        int64_t nsamples, int64_t rows_per_sample, float* partial, float* sums, lkgd_stream_t stream);
+int lkgd_groupnorm_finalize(const float* sums, int64_t nsamples, double count_per_group, float eps, float* stats,
+                            lkgd_stream_t stream);
 int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
                          int64_t nsamples, int64_t rows_per_sample, const float* stats, const float* gamma,
                          const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);
@@ -129,12 +138,14 @@ int lkgd_attn_spatial(const void* q, int32_t ldq, const void* k, int32_t ldk, co
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 5. Temporal self-attention: for every (batch b, pixel s, head h) attend over the F frames (F <= 32, head_dim 64).
+ *    q/out hold Fq query frames per batch entry, k/v hold Fk >= 1 key frames (Fq == Fk unless the frames of a clip
+ *    are sharded over GPUs: local queries against the all-gathered keys/values).
  *    Rows of q/k/v/out are tokens (b, f, s) - the [B*F,S,C] <-> [B*S,F,C] regroup of patch/patch.py:592-597,
  *    682-684 is an index map here, never a copy.  kv_b_map as in (4) (temporal joint branch :616-658).
  *    Replaces: TemporalBasicTransformerBlock.attn1 SDPA [EXT].
  * ------------------------------------------------------------------------------------------------------------- */
 int lkgd_attn_temporal(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
-                       void* out, int32_t ldo, int32_t B, int32_t F, int32_t S, int32_t heads,
+                       void* out, int32_t ldo, int32_t B, int32_t Fq, int32_t Fk, int32_t S, int32_t heads,
                        const int32_t* kv_b_map, float scale, lkgd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------

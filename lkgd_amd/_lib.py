@@ -28,8 +28,9 @@ class GemmDesc(C.Structure):
         ("mode", C.c_int32), ("Cin", C.c_int32),
         ("Hout", C.c_int32), ("Wout", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
         ("stride", C.c_int32), ("ups", C.c_int32),
-        ("F", C.c_int32), ("HW", C.c_int32),
+        ("F", C.c_int32), ("HW", C.c_int32), ("Floc", C.c_int32), ("f_off", C.c_int32),
         ("ldrb", C.c_int32), ("rb_d1", C.c_int32), ("rb_m1", C.c_int32), ("rb_d2", C.c_int32), ("rb_md", C.c_int32),
+        ("rb_c0", C.c_int32),
         ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("ldc", C.c_int32),
         ("s_acc", C.c_float), ("r1", C.c_float), ("r2", C.c_float),
         ("geglu", C.c_int32),
@@ -42,12 +43,14 @@ SYMBOLS = {
     "lkgd_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "lkgd_groupnorm_chunks": (_i32, [_i64, _i32]),
     "lkgd_groupnorm_stats": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp]),
+    "lkgd_groupnorm_sums": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "lkgd_groupnorm_finalize": (_i32, [_vp, _i64, C.c_double, _f32, _vp, _vp]),
     "lkgd_groupnorm_apply": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32,
                                     _vp]),
     "lkgd_layernorm": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
                               _vp]),
     "lkgd_attn_spatial": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),
-    "lkgd_attn_temporal": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _f32,
+    "lkgd_attn_temporal": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _f32,
                                   _vp]),
     "lkgd_prepare_unet_input": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "lkgd_cfg_euler_step": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),

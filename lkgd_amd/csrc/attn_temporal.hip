@@ -13,7 +13,7 @@ template <int FMAX>
 __global__ __launch_bounds__(FMAX * 16) void attn_temporal_kernel(const half_t* __restrict__ q, int ldq,
                                                             const half_t* __restrict__ k, int ldk,
                                                             const half_t* __restrict__ v, int ldv,
-                                                            half_t* __restrict__ out, int ldo, int F, int S,
+                                                            half_t* __restrict__ out, int ldo, int Fq, int F, int S,
                                                             int heads, const int* __restrict__ kvmap,
                                                             float scale_log2e) {
   const int t = threadIdx.x;
@@ -21,11 +21,11 @@ __global__ __launch_bounds__(FMAX * 16) void attn_temporal_kernel(const half_t* 
   const long long pid = (long long)blockIdx.x * 16 + (t & 15);
   const int b = blockIdx.y;
   const long long npairs = (long long)S * heads;
-  if (pid >= npairs || fq >= F) return;
+  if (pid >= npairs || fq >= Fq) return;
   const int s = (int)(pid / heads), hh = (int)(pid - (long long)s * heads);
   const int kvb = kvmap ? kvmap[b] : b;
 
-  const half_t* qp = q + (((long long)b * F + fq) * S + s) * ldq + hh * 64;
+  const half_t* qp = q + (((long long)b * Fq + fq) * S + s) * ldq + hh * 64;
   half8_t qv[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) qv[i] = *(const half8_t*)(qp + i * 8);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(FMAX * 16) void attn_temporal_kernel(const half_t* 
       }
     }
   }
-  half_t* op = out + (((long long)b * F + fq) * S + s) * ldo + hh * 64;
+  half_t* op = out + (((long long)b * Fq + fq) * S + s) * ldo + hh * 64;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     half8_t ov;
@@ -89,10 +89,10 @@ __global__ __launch_bounds__(FMAX * 16) void attn_temporal_kernel(const half_t* 
 }
 
 extern "C" int lkgd_attn_temporal(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
-                                  void* out, int32_t ldo, int32_t B, int32_t F, int32_t S, int32_t heads,
+                                  void* out, int32_t ldo, int32_t B, int32_t Fq, int32_t F, int32_t S, int32_t heads,
                                   const int32_t* kv_b_map, float scale, lkgd_stream_t stream) {
   if (!q || !k || !v || !out) return LKGD_E_NULL;
-  if (B <= 0 || F <= 0 || F > 32 || S <= 0 || heads <= 0 || B > 65535) return LKGD_E_SHAPE;
+  if (B <= 0 || F <= 0 || F > 32 || Fq <= 0 || Fq > F || S <= 0 || heads <= 0 || B > 65535) return LKGD_E_SHAPE;
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return LKGD_E_ALIGN;
   if (ldq < heads * 64 || ldk < heads * 64 || ldv < heads * 64 || ldo < heads * 64) return LKGD_E_SHAPE;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out)) return LKGD_E_ALIGN;
@@ -102,11 +102,11 @@ extern "C" int lkgd_attn_temporal(const void* q, int32_t ldq, const void* k, int
   const float c = scale * 1.4426950408889634f;
   if (F <= 16)
     hipLaunchKernelGGL(attn_temporal_kernel<16>, dim3((unsigned)nblk, B), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, F, S,
+                       (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, Fq, F, S,
                        heads, kv_b_map, c);
   else
     hipLaunchKernelGGL(attn_temporal_kernel<32>, dim3((unsigned)nblk, B), dim3(512), 0, (hipStream_t)stream,
-                       (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, F, S,
+                       (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, Fq, F, S,
                        heads, kv_b_map, c);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }

@@ -51,7 +51,7 @@ __device__ __forceinline__ const half_t* a_source(const lkgd_gemm_desc& p, const
     int c = k0 - tap * p.Cin + chunk * 8;
     int f = r.y + tap - 1;
     if ((unsigned)f >= (unsigned)p.F) return zero;
-    long long row = r.base + (long long)(tap - 1) * p.HW;
+    long long row = r.base + (long long)f * p.HW;
     return (const half_t*)p.a0 + row * p.lda0 + c;
   }
   // LKGD_A_CONV3X3_C8: one 16-byte chunk (8 channels) per tap
@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256, 2) void lkgd_gemm_kernel(const lkgd_gemm_desc 
         r.y = y * p.stride - 1;
         r.x = x * p.stride - 1;
       } else if (p.mode == LKGD_A_TCONV3) {
-        r.y = (m / p.HW) % p.F;
+        int bf = m / p.HW;                 // b*Floc + fl
+        int b = bf / p.Floc;
+        r.y = bf - b * p.Floc + p.f_off;   // global frame
+        r.base = (long long)b * p.F * p.HW + (m - (long long)bf * p.HW);   // + f*HW added per tap
       }
     }
     ar[i] = r;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void lkgd_gemm_kernel(const lkgd_gemm_desc 
         float4_t v = *(const float4_t*)(ct + row * BN + col);
         v += bias;
         if (rbp) {
-          long long idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2)) % p.rb_md;
+          long long idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
           half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + gcol);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
@@ -263,7 +266,7 @@ static int check_desc(const lkgd_gemm_desc* d) {
   if (!aligned16(d->a0) || !aligned16(d->w) || !aligned16(d->zeros) || ((uintptr_t)d->out & 7)) return LKGD_E_ALIGN;
   if (d->a1 && (!aligned16(d->a1) || d->lda1 % 8)) return LKGD_E_ALIGN;
   if (d->bias && !aligned16(d->bias)) return LKGD_E_ALIGN;
-  if (d->rowbias && (d->ldrb % 4 || d->rb_d1 <= 0 || d->rb_d2 <= 0 || d->rb_md <= 0)) return LKGD_E_SHAPE;
+  if (d->rowbias && (d->ldrb % 4 || d->rb_d1 <= 0 || d->rb_d2 <= 0 || d->rb_md <= 0 || d->rb_c0 < 0)) return LKGD_E_SHAPE;
   if (d->res1 && d->ldr1 % 4) return LKGD_E_ALIGN;
   if (d->res2 && d->ldr2 % 4) return LKGD_E_ALIGN;
   switch (d->mode) {
@@ -286,7 +289,8 @@ static int check_desc(const lkgd_gemm_desc* d) {
       break;
     case LKGD_A_TCONV3:
       if (d->Cin <= 0 || d->Cin % BK || d->K != 3 * d->Cin) return LKGD_E_SHAPE;
-      if (d->F <= 0 || d->HW <= 0 || d->M % (d->F * d->HW)) return LKGD_E_SHAPE;
+      if (d->F <= 0 || d->HW <= 0 || d->Floc <= 0 || d->f_off < 0 || d->f_off + d->Floc > d->F) return LKGD_E_SHAPE;
+      if (d->M % (d->Floc * d->HW)) return LKGD_E_SHAPE;
       break;
     case LKGD_A_CONV3X3_C8:
       if (d->Cin != 8 || d->K != 128 || d->lda0 != 8 || d->stride != 1 || d->ups != 0) return LKGD_E_SHAPE;

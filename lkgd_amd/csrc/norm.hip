@@ -95,6 +95,35 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, 
   }
 }
 
+// frame-sharded path: chunk partials -> raw fp32 sums per (sample, group); finalise from (all-reduced) sums
+__global__ __launch_bounds__(256) void gn_sums_kernel(const float* partial, int nchunks, float* sums) {
+  __shared__ float sh[8][GN_GROUPS][2];
+  const int t = threadIdx.x, g = t & 31, part = t >> 5;
+  const long long sample = blockIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int c = part; c < nchunks; c += 8) {
+    const float* p = partial + ((sample * nchunks + c) * GN_GROUPS + g) * 2;
+    a += p[0]; b += p[1];
+  }
+  sh[part][g][0] = (float)a; sh[part][g][1] = (float)b;
+  __syncthreads();
+  if (t < GN_GROUPS) {
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < 8; ++k) { sa += sh[k][t][0]; sb += sh[k][t][1]; }
+    sums[(sample * GN_GROUPS + t) * 2 + 0] = (float)sa;
+    sums[(sample * GN_GROUPS + t) * 2 + 1] = (float)sb;
+  }
+}
+__global__ void gn_finalize_sums_kernel(const float* sums, long long n, double inv_count, float eps, float* stats) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double mean = (double)sums[i * 2] * inv_count;
+  double var = (double)sums[i * 2 + 1] * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[i * 2] = (float)mean;
+  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0, int ld0, const half_t* x1, int c1,
                                                        int ld1, long long rows_per_sample, const float* stats,
                                                        const float* gamma, const float* beta, int silu,
@@ -166,6 +195,31 @@ extern "C" int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, con
   double inv = 1.0 / ((double)rows_per_sample * (double)((c0 + c1) / GN_GROUPS));
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
                      nchunks, inv, eps, stats);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+extern "C" int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
+                                   int64_t nsamples, int64_t rows_per_sample, float* partial, float* sums,
+                                   lkgd_stream_t stream) {
+  int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
+  if (rc) return rc;
+  if (!partial || !sums) return LKGD_E_NULL;
+  int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
+                     nchunks);
+  hipLaunchKernelGGL(gn_sums_kernel, dim3((unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial, nchunks,
+                     sums);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+extern "C" int lkgd_groupnorm_finalize(const float* sums, int64_t nsamples, double count_per_group, float eps,
+                                       float* stats, lkgd_stream_t stream) {
+  if (!sums || !stats) return LKGD_E_NULL;
+  if (nsamples <= 0 || !(count_per_group > 0.0)) return LKGD_E_SHAPE;
+  long long n = nsamples * GN_GROUPS;
+  hipLaunchKernelGGL(gn_finalize_sums_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     sums, n, 1.0 / count_per_group, eps, stats);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 

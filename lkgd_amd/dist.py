@@ -73,6 +73,21 @@ def make_plan(world: int, rank: int, num_frames: int, cfg: bool) -> ShardPlan:
     return ShardPlan(world, rank, cfg_groups, shards, ci, si, splits, sum(splits[:si]), num_frames)
 
 
+def _backend(group) -> str:
+    return dist.get_backend(group)
+
+
+def all_gather_into(buf: torch.Tensor, send: torch.Tensor, group=None) -> None:
+    """dist.all_gather_into_tensor; with the gloo backend (CPU tests / single-GPU functional tests) device tensors are
+    staged through host memory, RCCL ("nccl") takes the device pointers directly"""
+    if _backend(group) == "nccl" or not send.is_cuda:
+        dist.all_gather_into_tensor(buf, send, group=group)
+        return
+    hb, hs = torch.empty(buf.shape, dtype=buf.dtype), send.cpu()
+    dist.all_gather_into_tensor(hb, hs, group=group)
+    buf.copy_(hb)
+
+
 def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
     """local [f_local, ...] -> [num_frames, ...] over the frame group (padded equal-count all-gather + compaction)."""
     if plan.frame_shards == 1:
@@ -85,7 +100,7 @@ def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Ten
         send = torch.zeros((fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send[:plan.f_local].copy_(local)
     buf = torch.empty((plan.frame_shards * fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
+    all_gather_into(buf, send.contiguous(), group)
     if all(s == fmax for s in plan.splits):
         return buf
     out = torch.empty((plan.num_frames,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -99,5 +114,10 @@ def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Ten
 def allreduce_sums(sums: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
     """sum of the GroupNorm partial sums over the frame group (fp32, a few hundred bytes)"""
     if plan.frame_shards > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        if _backend(group) == "nccl" or not sums.is_cuda:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        else:
+            h = sums.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            sums.copy_(h)
     return sums

@@ -1,0 +1,129 @@
+"""Multi-GPU execution of ONE clip's denoising loop: CFG-parallel x frame slices, one process per GPU, RCCL.
+
+Exchange points per UNet forward on a rank (frame_shards > 1 only):
+  * each temporal GroupNorm  : all-reduce of [1,32,2] fp32 sums                       (22 blocks x 2)
+  * each temporal Conv3d     : all-gather of the normalised frame slices [F,HW,C]     (22 blocks x 2)
+  * each temporal attention  : all-gather of K|V [F,HW,2C]                            (16 blocks)
+and once per step, over ALL ranks, the all-gather of the noise prediction [cfg*F*HW, 4] (1 MB) before the replicated
+CFG-combine + Euler update.  With 2 GPUs (pure CFG-parallel) only the last exchange exists.
+
+Correctness notes
+  * every rank keeps the full latents (replicated, 1 MB) and the UNet weights; activations are sharded;
+  * the temporal cross-attention context of diffusers 0.27 interleaves the CFG halves' embeddings over pixels
+    (App. C11), so every rank evaluates the cross-attention bias table for BOTH embeddings;
+  * uneven frame slices (14 = 4+4+3+3) are padded to equal counts for RCCL's all-gather and compacted afterwards.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import LkgdHipError
+from .dist import ShardPlan, all_gather_into, allreduce_sums, gather_frames, make_plan
+
+
+class ShardInfo:
+    """what lkgd_amd.unet.Ctx needs to know about this rank's slice"""
+
+    def __init__(self, plan: ShardPlan, frame_group, HW_getter=None):
+        self.plan = plan
+        self.group = frame_group
+        self.F_total = plan.num_frames
+        self.f0 = plan.f0
+        self.B_total = plan.cfg_groups       # one clip: batch entries == CFG halves
+        self.b0 = plan.cfg_index
+
+    def gather(self, local: torch.Tensor) -> torch.Tensor:
+        """[f_local*HW, C] tokens -> [F*HW, C] over the frame group"""
+        fl = self.plan.f_local
+        x = local.reshape(fl, -1, local.shape[-1])
+        full = gather_frames(x, self.plan, self.group)
+        return full.reshape(-1, local.shape[-1])
+
+    def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
+        return allreduce_sums(sums, self.plan, self.group)
+
+
+class DistDenoiser:
+    def __init__(self, pipe, world: int, rank: int, num_frames: int, cfg: bool = True):
+        if not dist.is_initialized():
+            raise LkgdHipError("torch.distributed is not initialised")
+        self.pipe = pipe
+        self.plan = make_plan(world, rank, num_frames, cfg)
+        # every rank creates every group, in the same order
+        self.frame_group = None
+        for c in range(self.plan.cfg_groups):
+            ranks = list(range(c * self.plan.frame_shards, (c + 1) * self.plan.frame_shards))
+            g = dist.new_group(ranks) if self.plan.frame_shards > 1 else None
+            if c == self.plan.cfg_index:
+                self.frame_group = g
+        self.shard = ShardInfo(self.plan, self.frame_group)
+
+    @torch.no_grad()
+    def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, image_embeddings: torch.Tensor,
+                added_time_ids: torch.Tensor, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
+                max_guidance_scale: float = 3.0, domain_features: Optional[torch.Tensor] = None,
+                flow_features: Optional[torch.Tensor] = None) -> torch.Tensor:
+        pipe, plan = self.pipe, self.plan
+        unet, sch = pipe.unet, pipe.scheduler
+        dev = unet.device
+        B, F, _, H, W = latents.shape
+        if B != 1:
+            raise LkgdHipError("sharded denoising handles one clip (batch 1) per call")
+        cfg = 2 if max_guidance_scale > 1 else 1
+        if cfg != plan.cfg_groups and not (cfg == 2 and plan.cfg_groups == 1):
+            raise LkgdHipError("shard plan was built for classifier-free guidance; got guidance <= 1")
+        HW = H * W
+        latents = latents.to(dev).contiguous()
+        image_latents = image_latents.to(device=dev, dtype=torch.float16).contiguous()
+        sch.set_timesteps(num_inference_steps, device=None)
+        guidance = torch.linspace(min_guidance_scale, max_guidance_scale, F, dtype=torch.float32).to(dev)
+        enc = image_embeddings.to(dev)
+        if domain_features is not None:
+            enc = unet.fused_embedding(enc, domain_features.to(dev), flow_features.to(dev))
+        ids = added_time_ids.to(dev)
+        vpred = sch.config.prediction_type == "v_prediction"
+        fl, f0, fmax = plan.f_local, plan.f0, plan.f_max
+        if plan.cfg_groups == 2:
+            b_local, ids_local = 1, ids[plan.cfg_index:plan.cfg_index + 1]
+        else:
+            b_local, ids_local = cfg, ids
+        if b_local != 1 and plan.frame_shards > 1:
+            raise LkgdHipError("frame sharding without CFG-parallel needs guidance off (one batch entry per rank)")
+        send = torch.zeros(fmax * HW * b_local, 4, dtype=torch.float16, device=dev)
+        buf = torch.empty(plan.world * fmax * HW * b_local, 4, dtype=torch.float16, device=dev)
+        noise_full = torch.empty(cfg * F * HW, 4, dtype=torch.float16, device=dev)
+        for i, t in enumerate(sch.timesteps_host):
+            sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
+            tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)        # [cfg*F*HW, 8], replicated
+            if plan.cfg_groups == 2:
+                r0 = (plan.cfg_index * F + f0) * HW
+                tok_local = tok[r0:r0 + fl * HW]
+            else:
+                tok_local = tok.reshape(cfg, F, HW, 8)[:, f0:f0 + fl].reshape(-1, 8).contiguous()
+            noise_local, _ = unet.forward_tokens(tok_local, b_local, fl, H, W, t, enc, ids_local, shard=self.shard)
+            # ---- exchange the noise prediction over all ranks (padded equal counts), compact, replicate the update
+            if plan.cfg_groups == 2:
+                send[:fl * HW].copy_(noise_local)
+                all_gather_into(buf, send)
+                for r in range(plan.world):
+                    ci, si = divmod(r, plan.frame_shards)
+                    n, fs = plan.splits[si], sum(plan.splits[:si])
+                    noise_full[(ci * F + fs) * HW:(ci * F + fs + n) * HW].copy_(
+                        buf[r * fmax * HW:r * fmax * HW + n * HW])
+            else:
+                nl = noise_local.reshape(cfg, fl * HW, 4)
+                sv = send.reshape(cfg, fmax * HW, 4)
+                sv[:, :fl * HW].copy_(nl)
+                all_gather_into(buf, send)
+                bv = buf.reshape(plan.world, cfg, fmax * HW, 4)
+                nf = noise_full.reshape(cfg, F * HW, 4)
+                for r in range(plan.world):
+                    n, fs = plan.splits[r], sum(plan.splits[:r])
+                    nf[:, fs * HW:(fs + n) * HW].copy_(bv[r, :, :n * HW])
+            ops.cfg_euler_step(noise_full, latents, guidance, cfg, sigma, sigma_next, v_prediction=vpred)
+        sch._step_index = num_inference_steps
+        return latents

@@ -50,7 +50,7 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
-RowMap = Tuple[int, int, int, int]   # (d1, m1, d2, md): idx(row) = ((row // d1) * m1 + row % d2) % md
+RowMap = Tuple[int, ...]   # (d1, m1, d2, md[, c0]): idx(row) = ((row // d1) * m1 + row % d2 + c0) % md
 
 
 def rowmap_div(div: int) -> RowMap:
@@ -87,12 +87,14 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
         d.csplit = csplit if csplit is not None else Cin
     if conv is not None:
         d.Hout, d.Wout, d.Hin, d.Win, d.stride, d.ups = conv
-    if tconv is not None:
-        d.F, d.HW = tconv
+    if tconv is not None:      # (F, HW) or (F, HW, Floc, f_off) under frame sharding
+        d.F, d.HW = tconv[0], tconv[1]
+        d.Floc, d.f_off = (tconv[2], tconv[3]) if len(tconv) == 4 else (tconv[0], 0)
     if rowbias is not None:
         _req(rowbias, torch.float16, "rowbias")
         d.rowbias, d.ldrb = rowbias.data_ptr(), _ld(rowbias)
-        d.rb_d1, d.rb_m1, d.rb_d2, d.rb_md = rowmap
+        d.rb_d1, d.rb_m1, d.rb_d2, d.rb_md = rowmap[:4]
+        d.rb_c0 = rowmap[4] if len(rowmap) > 4 else 0
     if res1 is not None:
         _req(res1, torch.float16, "res1")
         d.res1, d.ldr1 = res1.data_ptr(), _ld(res1)
@@ -126,6 +128,29 @@ def groupnorm_stats(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int,
     check(L.lkgd_groupnorm_stats(x0.data_ptr(), c0, _ld(x0), _ptr(x1), c1, _ld(x1) if x1 is not None else 0,
                                  nsamples, rows_per_sample, eps, partial.data_ptr(), stats.data_ptr(), _stream()),
           "lkgd_groupnorm_stats")
+    return stats
+
+
+def groupnorm_sums(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, rows_per_sample: int) -> torch.Tensor:
+    """raw fp32 (sum, sumsq) per (sample, group) of the local rows (frame-sharded GroupNorm)"""
+    _req(x0, torch.float16, "x0")
+    c0 = x0.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    L = _lib.lib()
+    nchunks = L.lkgd_groupnorm_chunks(rows_per_sample, c0 + c1)
+    partial = torch.empty(nsamples * nchunks * 64, dtype=torch.float32, device=x0.device)
+    sums = torch.empty(nsamples, 32, 2, dtype=torch.float32, device=x0.device)
+    check(L.lkgd_groupnorm_sums(x0.data_ptr(), c0, _ld(x0), _ptr(x1), c1, _ld(x1) if x1 is not None else 0,
+                                nsamples, rows_per_sample, partial.data_ptr(), sums.data_ptr(), _stream()),
+          "lkgd_groupnorm_sums")
+    return sums
+
+
+def groupnorm_finalize(sums: torch.Tensor, count_per_group: float, eps: float) -> torch.Tensor:
+    _req(sums, torch.float32, "sums")
+    stats = torch.empty_like(sums)
+    check(_lib.lib().lkgd_groupnorm_finalize(sums.data_ptr(), sums.shape[0], float(count_per_group), eps,
+                                             stats.data_ptr(), _stream()), "lkgd_groupnorm_finalize")
     return stats
 
 
@@ -173,10 +198,12 @@ def attn_spatial(q, k, v, out, nbatch: int, S: int, heads: int, kv_batch_map: Op
 
 
 def attn_temporal(q, k, v, out, B: int, F: int, S: int, heads: int, kv_b_map: Optional[torch.Tensor] = None,
-                  scale: float = 0.125):
+                  scale: float = 0.125, Fq: Optional[int] = None):
+    """F = key/value frames; Fq = query frames (defaults to F; smaller under frame sharding)"""
     _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v")
     check(_lib.lib().lkgd_attn_temporal(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
-                                        out.data_ptr(), _ld(out), B, F, S, heads, _ptr(kv_b_map), scale, _stream()),
+                                        out.data_ptr(), _ld(out), B, Fq if Fq is not None else F, F, S, heads,
+                                        _ptr(kv_b_map), scale, _stream()),
           "lkgd_attn_temporal")
     return out
 

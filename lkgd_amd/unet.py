@@ -81,13 +81,25 @@ class UNetSpatioTemporalConditionOutput:
 class Ctx:
     """per-forward state: geometry, time-embedding table, cross-attention bias tables"""
 
-    def __init__(self, B: int, F: int, H: int, W: int, device):
-        self.B, self.F, self.H, self.W = B, F, H, W
+    def __init__(self, B: int, F: int, H: int, W: int, device, shard=None):
+        self.B, self.F, self.H, self.W = B, F, H, W      # LOCAL batch entries / frames
         self.device = device
+        # frame / CFG sharding over GPUs (lkgd_amd/dist_run.py); unsharded: totals == locals, offsets 0
+        self.shard = shard
+        self.F_total = shard.F_total if shard is not None else F
+        self.f0 = shard.f0 if shard is not None else 0
+        self.B_total = shard.B_total if shard is not None else B
+        self.b0 = shard.b0 if shard is not None else 0
+        if self.frames_sharded and B != 1:
+            raise LkgdHipError("frame sharding supports one batch entry per rank")
         self.temb_all: Optional[torch.Tensor] = None      # [B, sum C] fp16
         self.xb_all: Optional[torch.Tensor] = None        # [B, sum C] fp16
         self.spatial_partner: Optional[torch.Tensor] = None   # joint attention maps (patch API)
         self.temporal_partner: Optional[torch.Tensor] = None
+
+    @property
+    def frames_sharded(self) -> bool:
+        return self.F_total != self.F
 
     @property
     def N(self):
@@ -241,7 +253,7 @@ class BasicTransformerBlock(nn.Module):
         h1 = ctx.new(T, Cc)
         # attn1 out-projection + residual + (attn2 == per-batch bias, norm2/Q/K are dead for one key token)
         ops.gemm(att, pk.a1.wo, h1, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=h,
-                 rowbias=ctx.xb_all[:, pk.xoff:pk.xoff + Cc], rowmap=ops.rowmap_div(ctx.F * ctx.HW))
+                 rowbias=ctx.xb_all[ctx.b0:, pk.xoff:pk.xoff + Cc], rowmap=ops.rowmap_div(ctx.F * ctx.HW))
         if self.enable_joint_attention and hasattr(self, "attn1n"):
             h1 = self._joint(ctx, ln, h1)
         ln3 = ops.layernorm(h1, *pk.n3, 1e-5)
@@ -306,22 +318,32 @@ class TemporalBasicTransformerBlock(nn.Module):
         lnin = ops.layernorm(h_s, *pk.nin, 1e-5, rowbias=posemb, rowmap=fmap)
         m1 = _ff(ctx, pk.ffin, lnin, res1=h_s, rowbias=posemb, rowmap=fmap)        # ff_in(norm_in(m0)) + m0
         ln1 = ops.layernorm(m1, *pk.n1, 1e-5)
-        qkv = ctx.new(T, 3 * Cc)
-        ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
         att = ctx.new(T, Cc)
-        ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
-                          self.attn1.heads)
+        if not ctx.frames_sharded:
+            qkv = ctx.new(T, 3 * Cc)
+            ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+            ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
+                              self.attn1.heads)
+        else:
+            # frames of the clip live on several GPUs: local queries against the all-gathered keys / values
+            q, kv = ctx.new(T, Cc), ctx.new(T, 2 * Cc)
+            ops.gemm(ln1, pk.a1.wqkv[:Cc], q, M=T, N=Cc, K=Cc)
+            ops.gemm(ln1, pk.a1.wqkv[Cc:], kv, M=T, N=2 * Cc, K=Cc)
+            kvf = ctx.shard.gather(kv)
+            ops.attn_temporal(q, kvf[:, :Cc], kvf[:, Cc:], att, ctx.B, ctx.F_total, ctx.HW, self.attn1.heads,
+                              Fq=ctx.F)
+        xtab = ctx.xb_all[:, pk.xoff:pk.xoff + Cc]
         if isinstance(order, tuple):
             xmap = order                      # explicit context-row map (tests drive single blocks this way)
         elif order == "interleaved_0_27":
-            xmap = (ctx.F * ctx.HW, ctx.HW, ctx.HW, ctx.B)
+            # global row i = (b0 + b)*HW + s of the [B_total*HW, F, C] regroup uses context i % B_total
+            xmap = (ctx.F * ctx.HW, ctx.HW, ctx.HW, ctx.B_total, (ctx.b0 * ctx.HW) % ctx.B_total)
         elif order == "batch_major":
-            xmap = ops.rowmap_div(ctx.F * ctx.HW)
+            xmap, xtab = ops.rowmap_div(ctx.F * ctx.HW), ctx.xb_all[ctx.b0:, pk.xoff:pk.xoff + Cc]
         else:
             raise ValueError(order)
         m2 = ctx.new(T, Cc)
-        ops.gemm(att, pk.a1.wo, m2, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=m1,
-                 rowbias=ctx.xb_all[:, pk.xoff:pk.xoff + Cc], rowmap=xmap)
+        ops.gemm(att, pk.a1.wo, m2, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=m1, rowbias=xtab, rowmap=xmap)
         if self.enable_joint_attention and hasattr(self, "attn1n"):
             m2 = self._joint(ctx, ln1, m2)
         ln3 = ops.layernorm(m2, *pk.n3, 1e-5)
@@ -389,11 +411,11 @@ class TransformerSpatioTemporalModel(nn.Module):
 
     def _pos(self, ctx: Ctx) -> torch.Tensor:
         """frame positional embedding table [F, C]: step- and input-invariant -> computed once per frame count"""
-        e = self._posemb.get(ctx.F)
+        e = self._posemb.get(ctx.F_total)
         if e is None:
-            t = torch.arange(ctx.F, dtype=torch.float32, device=ctx.device)
+            t = torch.arange(ctx.F_total, dtype=torch.float32, device=ctx.device)
             e = self.time_pos_embed.run(ops.timestep_embedding(t, self.in_channels))
-            self._posemb[ctx.F] = e
+            self._posemb[ctx.F_total] = e
         return e
 
     def run(self, ctx: Ctx, x: torch.Tensor) -> torch.Tensor:
@@ -403,7 +425,7 @@ class TransformerSpatioTemporalModel(nn.Module):
         n = ops.groupnorm_silu(x, None, ctx.N, ctx.HW, *pk.gn, 1e-6, silu=False)
         h = ctx.new(T, Cc)
         ops.gemm(n, pk.win, h, M=T, N=Cc, K=Cc, bias=pk.bin)
-        posemb = self._pos(ctx)
+        posemb = self._pos(ctx)[ctx.f0:ctx.f0 + ctx.F]
         order = self.time_context_order or TIME_CONTEXT_ORDER
         for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
             h_s = blk.run(ctx, h)
@@ -485,16 +507,29 @@ class SpatioTemporalResBlock(nn.Module):
         s = ctx.new(T, Cout)
         ops.gemm(n2, pk.w2, s, M=T, N=Cout, K=9 * Cout, bias=pk.b2, mode=ops.A_CONV3X3, Cin=Cout, conv=geo, res1=sc)
         # --- TemporalResnetBlock on [B, C, F, H, W] == the same tokens; GroupNorm statistics span all F frames
-        n3 = ops.groupnorm_silu(s, None, ctx.B, ctx.F * ctx.HW, *pk.tn1, pk.teps)
+        n3 = self._temporal_norm(ctx, s, pk.tn1, pk.teps)
+        tgeo = (ctx.F_total, ctx.HW, ctx.F, ctx.f0)
         h = ctx.new(T, Cout)
         ops.gemm(n3, pk.tw1, h, M=T, N=Cout, K=3 * Cout, bias=pk.tb1, mode=ops.A_TCONV3, Cin=Cout,
-                 tconv=(ctx.F, ctx.HW), rowbias=ctx.temb_all[:, pk.toff_t:pk.toff_t + Cout], rowmap=bmap)
-        n4 = ops.groupnorm_silu(h, None, ctx.B, ctx.F * ctx.HW, *pk.tn2, pk.teps)
+                 tconv=tgeo, rowbias=ctx.temb_all[:, pk.toff_t:pk.toff_t + Cout], rowmap=bmap)
+        n4 = self._temporal_norm(ctx, h, pk.tn2, pk.teps)
         out = ctx.new(T, Cout)
         # temporal = s + conv2(..); AlphaBlender: alpha*s + (1-alpha)*temporal = s + (1-alpha)*conv2(..)
         ops.gemm(n4, pk.tw2, out, M=T, N=Cout, K=3 * Cout, bias=pk.tb2, mode=ops.A_TCONV3, Cin=Cout,
-                 tconv=(ctx.F, ctx.HW), s_acc=1.0 - pk.alpha, res1=s)
+                 tconv=tgeo, s_acc=1.0 - pk.alpha, res1=s)
         return out
+
+    @staticmethod
+    def _temporal_norm(ctx: Ctx, x: torch.Tensor, affine, eps: float) -> torch.Tensor:
+        """GroupNorm over (C/32, F, H, W) + SiLU, returned for ALL frames (the Conv3d that follows needs the +-1 frame
+        halo).  Sharded: all-reduce the [32,2] partial sums, normalise the local frames, all-gather them."""
+        if not ctx.frames_sharded:
+            return ops.groupnorm_silu(x, None, ctx.B, ctx.F * ctx.HW, *affine, eps)
+        sums = ctx.shard.allreduce(ops.groupnorm_sums(x, None, ctx.B, ctx.F * ctx.HW))
+        stats = ops.groupnorm_finalize(sums, float(ctx.F_total) * ctx.HW * (x.shape[1] // 32), eps)
+        local = ctx.new(x.shape[0], x.shape[1])
+        ops.groupnorm_apply(x, None, ctx.B, ctx.F * ctx.HW, stats, *affine, True, local)
+        return ctx.shard.gather(local)
 
 
 class Downsample2D(nn.Module):
@@ -848,9 +883,13 @@ class _UNetBase(nn.Module):
             raise LkgdHipError("encoder_hidden_states must be [batch, 1, cross_attention_dim] (one CLIP image token); "
                                "a multi-token context is outside the SVD hot path")
         pk = self._pk
-        e = encoder_hidden_states.to(device=ctx.device, dtype=torch.float16).reshape(ctx.B, -1).contiguous()
-        ctx.xb_all = torch.empty(ctx.B, pk.w_x.shape[0], dtype=torch.float16, device=ctx.device)
-        ops.gemm(e, pk.w_x, ctx.xb_all, M=ctx.B, N=pk.w_x.shape[0], K=pk.w_x.shape[1], bias=pk.b_x)
+        if encoder_hidden_states.shape[0] != ctx.B_total:
+            raise ValueError(f"encoder_hidden_states carries {encoder_hidden_states.shape[0]} entries, expected "
+                             f"{ctx.B_total}")
+        Bt = ctx.B_total       # under CFG sharding every rank still needs ALL contexts (App. C11 interleaving)
+        e = encoder_hidden_states.to(device=ctx.device, dtype=torch.float16).reshape(Bt, -1).contiguous()
+        ctx.xb_all = torch.empty(Bt, pk.w_x.shape[0], dtype=torch.float16, device=ctx.device)
+        ops.gemm(e, pk.w_x, ctx.xb_all, M=Bt, N=pk.w_x.shape[0], K=pk.w_x.shape[1], bias=pk.b_x)
 
     def _joint_maps(self, ctx: Ctx):
         """partner permutations of the patch API (patch/patch.py:454-475), computed on the host from the 4-entry mask"""
@@ -894,14 +933,17 @@ class _UNetBase(nn.Module):
 
     @torch.no_grad()
     def forward_tokens(self, tokens: torch.Tensor, B: int, F: int, H: int, W: int, timestep, encoder_hidden_states,
-                       added_time_ids, down_block_additional_residuals=None, mid_block_additional_residual=None):
+                       added_time_ids, down_block_additional_residuals=None, mid_block_additional_residual=None,
+                       shard=None):
         """channels-last entry: input tokens [B*F*H*W, 8] -> (noise tokens [B*F*H*W, 4], ctx).  This is what
         lkgd_amd.pipeline calls between the glue kernels (no NCHW conversions inside the loop)."""
         self.prepare()
-        ctx = Ctx(B, F, H, W, self.device)
+        ctx = Ctx(B, F, H, W, self.device, shard)
         pk = self._pk
         self._time_embed(ctx, timestep, added_time_ids)
         self._cross_tables(ctx, encoder_hidden_states)
+        if shard is not None and getattr(self, "_joint_attn_mask", None) is not None:
+            raise LkgdHipError("joint attention (patch API) pairs batch entries and is not available under sharding")
         self._joint_maps(ctx)
         h = ctx.new(ctx.T, pk.w_in.shape[0])
         ops.gemm(tokens, pk.w_in, h, M=ctx.T, N=pk.w_in.shape[0], K=128, bias=pk.b_in, mode=ops.A_CONV3X3_C8, Cin=8,

@@ -1,0 +1,78 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the frame-parallel host logic: shard plans, the padded uneven
+all-gather of frame slices, the GroupNorm partial-sum all-reduce.  The kernels themselves are covered by -m gpu tests
+(tests/test_dist_gpu.py runs the sharded UNet with two ranks on one GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lkgd_amd.dist import allreduce_sums, gather_frames, make_plan, split_frames
+
+
+def test_split_and_plans():
+    assert split_frames(14, 4) == (4, 4, 3, 3) and split_frames(14, 2) == (7, 7) and split_frames(14, 1) == (14,)
+    assert split_frames(25, 4) == (7, 6, 6, 6)
+    with pytest.raises(ValueError):
+        split_frames(3, 4)
+    p = make_plan(8, 6, 14, cfg=True)          # CFG(2) x frames(4,4,3,3)
+    assert (p.cfg_groups, p.frame_shards, p.cfg_index, p.shard_index) == (2, 4, 1, 2)
+    assert p.f0 == 8 and p.f_local == 3 and p.f_max == 4
+    assert p.frame_group_ranks() == [4, 5, 6, 7] and p.cfg_partner_ranks() == [2, 6]
+    p = make_plan(2, 1, 14, cfg=True)          # pure CFG-parallel: no frame exchange at all
+    assert p.frame_shards == 1 and p.cfg_index == 1 and p.f_local == 14
+    p = make_plan(4, 3, 14, cfg=False)         # guidance off: all ranks share the frames
+    assert p.cfg_groups == 1 and p.splits == (4, 4, 3, 3) and p.f0 == 11
+    covered = []
+    for r in range(8):
+        q = make_plan(8, r, 14, True)
+        covered.append((q.cfg_index, q.f0, q.f0 + q.f_local))
+    assert sorted(covered) == [(0, 0, 4), (0, 4, 8), (0, 8, 11), (0, 11, 14), (1, 0, 4), (1, 4, 8), (1, 8, 11),
+                               (1, 11, 14)]
+    with pytest.raises(ValueError):
+        make_plan(3, 0, 14, cfg=True)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, frames, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = make_plan(world, rank, frames, cfg=False)
+        full = torch.arange(frames * 3 * 5, dtype=torch.float32).reshape(frames, 3, 5)
+        local = full[plan.f0:plan.f0 + plan.f_local].clone()
+        got = gather_frames(local, plan)
+        ok = torch.equal(got, full)
+        sums = torch.full((1, 32, 2), float(rank + 1))
+        allreduce_sums(sums, plan)
+        ok = ok and torch.equal(sums, torch.full((1, 32, 2), float(sum(range(1, world + 1)))))
+        # fp16 payload, as the activations are
+        h = gather_frames(local.half(), plan)
+        ok = ok and torch.equal(h, full.half())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("frames", [4, 5, 14, 3])
+def test_uneven_frame_gather_world2(frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,124 @@
+"""Sharded denoising loop on the MI355X box: W processes share cuda:0 and talk over gloo (the 1-GPU box cannot host an
+RCCL world), each running the HIP path on its CFG half / frame slice.  Result must equal the single-process loop within
+fp16 reduction-order noise.  Pure CFG-parallel (2 ranks) is bit-identical work and must agree to 1e-3 (SURVEY.md 8e
+"Determinism").  With frame slices the temporal GroupNorm sums are reduced in a different order (fp32, last-bit), and
+the random-init tiny UNet amplifies a ONE-ulp fp16 perturbation of its input to 4.0e-3 relative on the output
+(measured: tools/dist_noise_experiment.py -> sharded 3.2e-3, rerun 0.0, ulp-perturbed 4.0e-3), so the gate there is
+8e-3; the sharded kernel variants themselves are pinned bit-exactly in test_sharded_kernel_variants_are_exact."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(frames, guidance_on):
+    g = torch.Generator().manual_seed(77)
+    lat0 = torch.randn(1, frames, 4, 8, 8, generator=g)
+    img = 0.18215 * torch.randn(1, 1, 4, 8, 8, generator=g).repeat(1, frames, 1, 1, 1)
+    emb = torch.randn(1, 1, 1024, generator=g)
+    if guidance_on:
+        img = torch.cat([torch.zeros_like(img), img])
+        emb = torch.cat([torch.zeros_like(emb), emb])
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * (2 if guidance_on else 1))
+    return lat0, img, emb, ids
+
+
+def _build(dev):
+    from lkgd_amd import unet as pu
+    m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig(
+        sample_size=8, block_out_channels=(64, 128, 128, 128), num_attention_heads=(1, 2, 2, 2),
+        addition_time_embed_dim=64, projection_class_embeddings_input_dim=192, num_frames=4))
+    m = m.half().to(dev)
+    pu.init_synthetic_weights_(m, seed=5)      # same seed on every rank -> replicated weights
+    return m
+
+
+def _worker(rank, world, port, frames, guidance_on, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkgd_amd.dist_run import DistDenoiser
+        from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+        dev = torch.device("cuda", 0)
+        pipe = StableVideoDiffusionPipeline(unet=_build(dev))
+        lat0, img, emb, ids = _inputs(frames, guidance_on)
+        gmax = 3.0 if guidance_on else 1.0
+        pipe.scheduler.set_timesteps(2)
+        s0 = float(pipe.scheduler.init_noise_sigma)
+        runner = DistDenoiser(pipe, world, rank, frames, cfg=guidance_on)
+        out = runner.denoise((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2, 1.0,
+                             gmax)
+        res = {"rank": rank, "out": out.float().cpu()}
+        if rank == 0:
+            ref = pipe.denoise((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2,
+                               1.0, gmax)
+            res["ref"] = ref.float().cpu()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames,guidance_on", [(2, 4, True), (4, 5, True), (2, 5, False), (4, 6, False)])
+def test_sharded_loop_equals_single_process(world, frames, guidance_on):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, frames, guidance_on, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = [r["ref"] for r in results if "ref" in r][0]
+    assert torch.isfinite(ref).all()
+    for r in results:
+        rel = ((r["out"] - ref).norm() / ref.norm()).item()
+        tol = 1e-3 if (world == 2 and guidance_on) else 8e-3
+        assert rel <= tol, f"rank {r['rank']}: sharded vs single-process relative L2 {rel:.3e} (tol {tol})"
+
+
+def test_sharded_kernel_variants_are_exact():
+    """frame-offset Conv3d gather, Fq < Fk temporal attention and sums+finalize GroupNorm vs their unsharded forms"""
+    import torch.nn.functional as F
+    from lkgd_amd import ops
+    from lkgd_amd.packing import pack_tconv3
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    B, Fr, HW, C = 1, 5, 24, 64
+    x = torch.randn(B * Fr * HW, C, generator=g).half().to(dev)
+    w = pack_tconv3(torch.randn(C, C, 3, 1, 1, generator=g) / 14).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    full = torch.empty(B * Fr * HW, C, dtype=torch.float16, device=dev)
+    ops.gemm(x, w, full, M=B * Fr * HW, N=C, K=3 * C, bias=bias, mode=ops.A_TCONV3, Cin=C, tconv=(Fr, HW))
+    for f0, fl in ((0, 3), (3, 2), (1, 1), (4, 1)):
+        part = torch.empty(fl * HW, C, dtype=torch.float16, device=dev)
+        ops.gemm(x, w, part, M=fl * HW, N=C, K=3 * C, bias=bias, mode=ops.A_TCONV3, Cin=C, tconv=(Fr, HW, fl, f0))
+        assert torch.equal(part, full[f0 * HW:(f0 + fl) * HW]), (f0, fl)
+    heads = 1
+    qkv = torch.randn(Fr * HW, 3 * C, generator=g).half().to(dev)
+    att = torch.empty(Fr * HW, C, dtype=torch.float16, device=dev)
+    ops.attn_temporal(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], att, 1, Fr, HW, heads)
+    for f0, fl in ((0, 3), (3, 2)):
+        q = qkv[f0 * HW:(f0 + fl) * HW, :C].contiguous()
+        o = torch.empty(fl * HW, C, dtype=torch.float16, device=dev)
+        ops.attn_temporal(q, qkv[:, C:2 * C], qkv[:, 2 * C:], o, 1, Fr, HW, heads, Fq=fl)
+        assert torch.equal(o, att[f0 * HW:(f0 + fl) * HW])
+    stats = ops.groupnorm_stats(x, None, 1, Fr * HW, 1e-5)
+    s1 = ops.groupnorm_sums(x[:3 * HW], None, 1, 3 * HW)
+    s2 = ops.groupnorm_sums(x[3 * HW:], None, 1, 2 * HW)
+    st = ops.groupnorm_finalize(s1 + s2, float(Fr * HW * (C // 32)), 1e-5)
+    torch.testing.assert_close(st, stats, rtol=2e-6, atol=2e-6)
