@@ -1,0 +1,229 @@
+// Shared pieces of the MFMA GEMM kernels: the implicit-convolution A-operand gather and the epilogue row map.
+#pragma once
+#include "common.h"
+
+#define BK 64
+
+struct ARow {
+  long long base;  // mode-specific row base (token index of the source image / row)
+  int y, x;        // conv: top-left of the 3x3 window in the (virtual) source grid; tconv: frame index in y
+  int valid;
+};
+
+__device__ __forceinline__ const half_t* a_source(const lkgd_gemm_desc& p, const ARow& r, int k0, int chunk) {
+  const half_t* zero = (const half_t*)p.zeros;
+  if (!r.valid) return zero;
+  if (p.mode == LKGD_A_PLAIN) {
+    int k = k0 + chunk * 8;
+    if (k < p.csplit) return (const half_t*)p.a0 + r.base * p.lda0 + k;
+    return (const half_t*)p.a1 + r.base * p.lda1 + (k - p.csplit);
+  }
+  if (p.mode == LKGD_A_CONV3X3) {
+    int tap = k0 / p.Cin;
+    int c = k0 - tap * p.Cin + chunk * 8;
+    int ky = tap / 3, kx = tap - ky * 3;
+    int vy = r.y + ky, vx = r.x + kx;
+    int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+    if ((unsigned)vy >= (unsigned)Hv || (unsigned)vx >= (unsigned)Wv) return zero;
+    long long row = r.base + (long long)(vy >> p.ups) * p.Win + (vx >> p.ups);
+    if (c < p.csplit) return (const half_t*)p.a0 + row * p.lda0 + c;
+    return (const half_t*)p.a1 + row * p.lda1 + (c - p.csplit);
+  }
+  if (p.mode == LKGD_A_TCONV3) {
+    int tap = k0 / p.Cin;
+    int c = k0 - tap * p.Cin + chunk * 8;
+    int f = r.y + tap - 1;
+    if ((unsigned)f >= (unsigned)p.F) return zero;
+    long long row = r.base + (long long)f * p.HW;
+    return (const half_t*)p.a0 + row * p.lda0 + c;
+  }
+  // LKGD_A_CONV3X3_C8: one 16-byte chunk (8 channels) per tap
+  int tap = (k0 >> 3) + chunk;
+  if (tap >= 9) return zero;
+  int ky = tap / 3, kx = tap - ky * 3;
+  int vy = r.y + ky, vx = r.x + kx;
+  if ((unsigned)vy >= (unsigned)p.Hin || (unsigned)vx >= (unsigned)p.Win) return zero;
+  long long row = r.base + (long long)vy * p.Win + vx;
+  return (const half_t*)p.a0 + row * p.lda0;
+}
+
+
+// per-thread decomposition of output row m into the gather state of its mode
+__device__ __forceinline__ ARow a_row(const lkgd_gemm_desc& p, int m) {
+  ARow r;
+  r.valid = m < p.M;
+  r.base = m; r.y = 0; r.x = 0;
+  if (r.valid) {
+    if (p.mode == LKGD_A_CONV3X3 || p.mode == LKGD_A_CONV3X3_C8) {
+      int hw = p.Hout * p.Wout;
+      int n = m / hw, rem = m - n * hw;
+      int y = rem / p.Wout, x = rem - y * p.Wout;
+      r.base = (long long)n * p.Hin * p.Win;
+      r.y = y * p.stride - 1;
+      r.x = x * p.stride - 1;
+    } else if (p.mode == LKGD_A_TCONV3) {
+      int bf = m / p.HW;                 // b*Floc + fl
+      int b = bf / p.Floc;
+      r.y = bf - b * p.Floc + p.f_off;   // global frame
+      r.base = (long long)b * p.F * p.HW + (m - (long long)bf * p.HW);   // + f*HW added per tap
+    }
+  }
+  return r;
+}
+
+// ---- segment-wise A gather --------------------------------------------------------------------------------------
+// K is walked in BK chunks; consecutive chunks stay inside one "segment" = (3x3 / temporal tap, source tensor) for
+// Cin/64 (or csplit/64) chunks.  All the per-lane address work (halo test, upsample shift, frame shift, concat source
+// select) is done ONCE per segment; inside a segment a chunk's source is `ptr + (k0 - seg_k0)` (zero page rows stay).
+template <int NR>
+struct AGather {
+  const half_t* ptr[NR];
+  ARow row[NR];
+  unsigned zmask;        // bit i: row i reads the zero page in this segment
+  int seg_k0, seg_end;
+};
+
+template <int NR>
+__device__ __forceinline__ void a_segment(const lkgd_gemm_desc& p, AGather<NR>& g, int k0, int schunk) {
+  const half_t* zero = (const half_t*)p.zeros;
+  g.zmask = 0;
+  if (p.mode == LKGD_A_PLAIN) {
+    const bool s1 = k0 >= p.csplit;
+    g.seg_k0 = s1 ? p.csplit : 0;
+    g.seg_end = s1 ? p.K : (p.csplit < p.K ? p.csplit : p.K);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const ARow& r = g.row[i];
+      const half_t* q = s1 ? (const half_t*)p.a1 + r.base * p.lda1 : (const half_t*)p.a0 + r.base * p.lda0;
+      g.ptr[i] = r.valid ? q + schunk * 8 : zero;
+      g.zmask |= (r.valid ? 0u : 1u) << i;
+    }
+  } else if (p.mode == LKGD_A_CONV3X3) {
+    const int tap = k0 / p.Cin;
+    const int c = k0 - tap * p.Cin;
+    const bool s1 = c >= p.csplit;
+    g.seg_k0 = tap * p.Cin + (s1 ? p.csplit : 0);
+    g.seg_end = tap * p.Cin + (s1 ? p.Cin : (p.csplit < p.Cin ? p.csplit : p.Cin));
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const ARow& r = g.row[i];
+      const int vy = r.y + ky, vx = r.x + kx;
+      const bool ok = r.valid && (unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv;
+      const long long rowi = r.base + (long long)(vy >> p.ups) * p.Win + (vx >> p.ups);
+      const half_t* q = s1 ? (const half_t*)p.a1 + rowi * p.lda1 : (const half_t*)p.a0 + rowi * p.lda0;
+      g.ptr[i] = ok ? q + schunk * 8 : zero;
+      g.zmask |= (ok ? 0u : 1u) << i;
+    }
+  } else if (p.mode == LKGD_A_TCONV3) {
+    const int tap = k0 / p.Cin;
+    g.seg_k0 = tap * p.Cin;
+    g.seg_end = g.seg_k0 + p.Cin;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const ARow& r = g.row[i];
+      const int f = r.y + tap - 1;
+      const bool ok = r.valid && (unsigned)f < (unsigned)p.F;
+      const long long rowi = r.base + (long long)f * p.HW;
+      g.ptr[i] = ok ? (const half_t*)p.a0 + rowi * p.lda0 + schunk * 8 : zero;
+      g.zmask |= (ok ? 0u : 1u) << i;
+    }
+  } else {   // LKGD_A_CONV3X3_C8: one tap per 16-byte chunk - every K-tile is its own segment
+    g.seg_k0 = k0;
+    g.seg_end = k0 + BK;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      g.ptr[i] = a_source(p, g.row[i], k0, schunk);
+      g.zmask |= 1u << i;     // pointer is final: no in-segment offset
+    }
+  }
+}
+
+// source of row i's chunk for K-tile k0 (k0 must lie in the current segment)
+template <int NR>
+__device__ __forceinline__ const half_t* a_chunk(const AGather<NR>& g, int i, int k0) {
+  const int off = ((g.zmask >> i) & 1u) ? 0 : (k0 - g.seg_k0);
+  return g.ptr[i] + off;
+}
+
+// XCD-aware, bijective block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), so each residue class
+// gets a contiguous range of tiles; inside the range n is fastest (the A tile is reused from that XCD's L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  int xcd = bid & 7, slot = bid >> 3;
+  int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// shared epilogue on an fp32 C tile staged in LDS (row pitch BN_ floats): bias, row-indexed bias, scale, two residuals
+// or GEGLU; NT threads, 8-byte row-contiguous stores
+template <int BM_, int BN_, int NT>
+__device__ __forceinline__ void gemm_epilogue(const lkgd_gemm_desc& p, const float* ct, int t, int m0, int n0,
+                                              int tn) {
+  const half_t* rbp = (const half_t*)p.rowbias;
+  const half_t* r1p = (const half_t*)p.res1;
+  const half_t* r2p = (const half_t*)p.res2;
+  half_t* outp = (half_t*)p.out;
+  if (!p.geglu) {
+    constexpr int TPR = BN_ / 4;            // threads per row
+    constexpr int RPP = NT / TPR;           // rows per pass
+    const int col = (t % TPR) * 4;
+    const int gcol = n0 + col;
+    if (gcol < p.N) {
+      float4_t bias = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias = *(const float4_t*)(p.bias + gcol);
+#pragma unroll 4
+      for (int it = 0; it < BM_ / RPP; ++it) {
+        int row = (t / TPR) + RPP * it;
+        long long m = m0 + row;
+        if (m >= p.M) break;
+        float4_t v = *(const float4_t*)(ct + row * BN_ + col);
+        v += bias;
+        if (rbp) {
+          long long idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
+          half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + gcol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
+        }
+        v *= p.s_acc;
+        if (r1p) {
+          half4_t r = *(const half4_t*)(r1p + m * p.ldr1 + gcol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += p.r1 * (float)r[e];
+        }
+        if (r2p) {
+          half4_t r = *(const half4_t*)(r2p + m * p.ldr2 + gcol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += p.r2 * (float)r[e];
+        }
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+        *(half4_t*)(outp + m * p.ldc + gcol) = o;
+      }
+    }
+  } else {
+    // tile columns [0,64) = hidden, [64,128) = gate of output columns tn*64 + [0,64)
+    static_assert(BN_ == 128, "GEGLU tile interleave is 64 hidden | 64 gate");
+    constexpr int RPP = NT / 16;
+    const int col = (t & 15) * 4;
+    const int ocol = tn * 64 + col;
+    float4_t bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      bh = *(const float4_t*)(p.bias + n0 + col);
+      bg = *(const float4_t*)(p.bias + n0 + 64 + col);
+    }
+#pragma unroll 4
+    for (int it = 0; it < BM_ / RPP; ++it) {
+      int row = (t >> 4) + RPP * it;
+      long long m = m0 + row;
+      if (m >= p.M) break;
+      float4_t hv = *(const float4_t*)(ct + row * BN_ + col) + bh;
+      float4_t gv = *(const float4_t*)(ct + row * BN_ + 64 + col) + bg;
+      half4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(hv[e] * gelu_erf_f(gv[e]));
+      *(half4_t*)(outp + m * p.ldc + ocol) = o;
+    }
+  }
+}

@@ -24,10 +24,13 @@ def _close(got, ref, rtol=4e-3, what=""):
     assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
 
 
-@pytest.fixture(scope="module")
-def ops():
-    from lkgd_amd import ops
-    return ops
+@pytest.fixture(scope="module", params=["tile128", "tile256"])
+def ops(request):
+    """every GEMM/conv test runs against BOTH kernel variants (128x128 two-stage, 256x128 three-stage ring)"""
+    from lkgd_amd import _lib, ops
+    _lib.lib().lkgd_debug_set_gemm_variant(1 if request.param == "tile128" else 2)
+    yield ops
+    _lib.lib().lkgd_debug_set_gemm_variant(0)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (1000, 64, 1280), (2, 1280, 320), (4032, 960, 640)])
