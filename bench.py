@@ -122,13 +122,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" == RCCL on ROCm.  LKGD_DIST_BACKEND=gloo is a functional-test knob for boxes with fewer GPUs than ranks
+        backend = os.environ.get("LKGD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from lkgd_amd import ops
     from lkgd_amd.pipeline import StableVideoDiffusionPipeline
