@@ -279,7 +279,10 @@ static int check_desc(const lkgd_gemm_desc* d) {
   return LKGD_OK;
 }
 
-// tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128
+extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
+
+// tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128 ring,
+// 3 = force the persistent streaming kernel
 static int gemm_variant_override = 0;
 extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = v; }
 
@@ -294,6 +297,16 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
                             GEMM2_LDS) != hipSuccess)
       return LKGD_E_LAUNCH;
     attr_set = true;
+  }
+  if (gemm_variant_override == 3 || (gemm_variant_override == 0 && d->M > 256)) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LKGD_E_LAUNCH;
+      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
   }
   int tiles_n = (d->N + BN - 1) / BN;
   // deep-K problems (3x3 / temporal convs, K >= 960) take the 256x128 three-stage ring: its two K-tiles in flight hide

@@ -203,15 +203,16 @@ __device__ __forceinline__ void gemm_epilogue(const lkgd_gemm_desc& p, const flo
       }
     }
   } else {
-    // tile columns [0,64) = hidden, [64,128) = gate of output columns tn*64 + [0,64)
-    static_assert(BN_ == 128, "GEGLU tile interleave is 64 hidden | 64 gate");
+    // tile columns: [0,32) hidden 0-31 | [32,64) gate 0-31 | [64,96) hidden 32-63 | [96,128) gate 32-63
+    static_assert(BN_ == 128, "GEGLU tile interleave is 32 hidden | 32 gate | 32 hidden | 32 gate");
     constexpr int RPP = NT / 16;
-    const int col = (t & 15) * 4;
-    const int ocol = tn * 64 + col;
+    const int oc = (t & 15) * 4;                 // output column inside the tile's 64
+    const int col = (oc >> 5) * 64 + (oc & 31);  // its hidden column in the tile; gate = +32
+    const int ocol = tn * 64 + oc;
     float4_t bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
       bh = *(const float4_t*)(p.bias + n0 + col);
-      bg = *(const float4_t*)(p.bias + n0 + 64 + col);
+      bg = *(const float4_t*)(p.bias + n0 + 32 + col);
     }
 #pragma unroll 4
     for (int it = 0; it < BM_ / RPP; ++it) {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void gemm_epilogue(const lkgd_gemm_desc& p, const flo
       long long m = m0 + row;
       if (m >= p.M) break;
       float4_t hv = *(const float4_t*)(ct + row * BN_ + col) + bh;
-      float4_t gv = *(const float4_t*)(ct + row * BN_ + 64 + col) + bg;
+      float4_t gv = *(const float4_t*)(ct + row * BN_ + 32 + col) + bg;
       half4_t o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (half_t)(hv[e] * gelu_erf_f(gv[e]));

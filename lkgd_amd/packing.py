@@ -34,10 +34,10 @@ def pack_tconv3(w: torch.Tensor) -> torch.Tensor:
 
 
 def geglu_perm(inner: int, device=None) -> torch.Tensor:
-    """row permutation of the GEGLU projection [2*inner, K]: tile tn (128 rows) = 64 hidden rows tn*64.. followed by
-    their 64 gate rows inner + tn*64.."""
+    """row permutation of the GEGLU projection [2*inner, K]: every 64 packed rows = 32 hidden rows followed by their 32
+    gate rows (inner + ..), so that the 64 output columns one wave owns hold both factors of 32 GEGLU outputs"""
     assert inner % 64 == 0
-    t = torch.arange(inner // 64, device=device)[:, None] * 64 + torch.arange(64, device=device)[None, :]
+    t = torch.arange(inner // 32, device=device)[:, None] * 32 + torch.arange(32, device=device)[None, :]
     return torch.cat([t, t + inner], dim=1).reshape(-1)
 
 

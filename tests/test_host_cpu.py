@@ -86,8 +86,8 @@ def test_packing_layouts():
     p = pk.pack_tconv3(wt)
     assert torch.equal(p[3, 2 * 4 + 1], wt[3, 1, 2, 0, 0].half())
     perm = pk.geglu_perm(128)
-    assert perm[:64].tolist() == list(range(64)) and perm[64:128].tolist() == list(range(128, 192))
-    assert perm[128:192].tolist() == list(range(64, 128)) and sorted(perm.tolist()) == list(range(256))
+    assert perm[:32].tolist() == list(range(32)) and perm[32:64].tolist() == list(range(128, 160))
+    assert perm[64:96].tolist() == list(range(32, 64)) and sorted(perm.tolist()) == list(range(256))
 
 
 def test_patch_api_bookkeeping():

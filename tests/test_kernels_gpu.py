@@ -24,11 +24,12 @@ def _close(got, ref, rtol=4e-3, what=""):
     assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
 
 
-@pytest.fixture(scope="module", params=["tile128", "tile256"])
+@pytest.fixture(scope="module", params=["tile128", "tile256", "stream"])
 def ops(request):
-    """every GEMM/conv test runs against BOTH kernel variants (128x128 two-stage, 256x128 three-stage ring)"""
+    """every GEMM/conv test runs against ALL kernel variants (128x128 two-stage, 256x128 three-stage ring, persistent
+    streaming kernel with register epilogue)"""
     from lkgd_amd import _lib, ops
-    _lib.lib().lkgd_debug_set_gemm_variant(1 if request.param == "tile128" else 2)
+    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3}[request.param])
     yield ops
     _lib.lib().lkgd_debug_set_gemm_variant(0)
 
@@ -43,6 +44,22 @@ def test_gemm_plain_bias_residual(ops, M, N, K):
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
     ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=bias.to(DEV), res1=res.to(DEV), r1=0.5)
     _close(out, ref, what="gemm plain")
+
+
+def test_gemm_many_tiles_short_k(ops):
+    """> 256 output tiles with K = 64/128 (epilogue every 1-2 K-steps), ragged M and N: stresses the streaming ring"""
+    g = torch.Generator().manual_seed(77)
+    for M, N, K in ((256 * 70 + 37, 320, 64), (256 * 41 + 200, 704, 128), (256 * 300, 128, 192)):
+        a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+        bias = torch.randn(N, generator=g)
+        res = _h(torch.randn(M, N, generator=g))
+        ref = a.float() @ w.float().T + bias + res.float()
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+        ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=bias.to(DEV), res1=res.to(DEV))
+        _close(out, ref, what=f"gemm many tiles {M}x{N}x{K}")
+        out2 = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+        ops.gemm(a.to(DEV), w.to(DEV), out2, M=M, N=N, K=K)       # no epilogue loads at all
+        _close(out2, a.float() @ w.float().T, what="gemm many tiles, bare")
 
 
 def test_gemm_two_source_and_blend(ops):
