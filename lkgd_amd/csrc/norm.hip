@@ -71,47 +71,45 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, int c0,
 }
 
 // Both reduction stages run in a fixed order: results are bitwise reproducible.  Statistics are fp32 over fp16 data,
-// combined across chunks in fp64.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, int nchunks, double inv_count,
-                                                          float eps, float* stats) {
-  __shared__ float sh[8][GN_GROUPS][2];
-  const int t = threadIdx.x, g = t & 31, part = t >> 5;
-  const long long sample = blockIdx.x;
+// combined across chunks in fp64.  One wave per (sample, group): lanes stride over the chunks, fixed-order butterfly.
+__device__ __forceinline__ void gn_reduce_pair(const float* partial, int nchunks, long long sample, int g, int lane,
+                                               double& sa, double& sb) {
   double a = 0.0, b = 0.0;
-  for (int c = part; c < nchunks; c += 8) {
+  for (int c = lane; c < nchunks; c += 64) {
     const float* p = partial + ((sample * nchunks + c) * GN_GROUPS + g) * 2;
     a += p[0]; b += p[1];
   }
-  sh[part][g][0] = (float)a; sh[part][g][1] = (float)b;
-  __syncthreads();
-  if (t < GN_GROUPS) {
-    double sa = 0.0, sb = 0.0;
-    for (int k = 0; k < 8; ++k) { sa += sh[k][t][0]; sb += sh[k][t][1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  sa = a; sb = b;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, int nchunks, double inv_count,
+                                                          float eps, float* stats) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);      // 8 workgroups x 4 waves = 32 groups
+  const long long sample = blockIdx.y;
+  double sa, sb;
+  gn_reduce_pair(partial, nchunks, sample, g, lane, sa, sb);
+  if (lane == 0) {
     double mean = sa * inv_count;
     double var = sb * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
-    stats[(sample * GN_GROUPS + t) * 2 + 0] = (float)mean;
-    stats[(sample * GN_GROUPS + t) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    stats[(sample * GN_GROUPS + g) * 2 + 0] = (float)mean;
+    stats[(sample * GN_GROUPS + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
 // frame-sharded path: chunk partials -> raw fp32 sums per (sample, group); finalise from (all-reduced) sums
 __global__ __launch_bounds__(256) void gn_sums_kernel(const float* partial, int nchunks, float* sums) {
-  __shared__ float sh[8][GN_GROUPS][2];
-  const int t = threadIdx.x, g = t & 31, part = t >> 5;
-  const long long sample = blockIdx.x;
-  double a = 0.0, b = 0.0;
-  for (int c = part; c < nchunks; c += 8) {
-    const float* p = partial + ((sample * nchunks + c) * GN_GROUPS + g) * 2;
-    a += p[0]; b += p[1];
-  }
-  sh[part][g][0] = (float)a; sh[part][g][1] = (float)b;
-  __syncthreads();
-  if (t < GN_GROUPS) {
-    double sa = 0.0, sb = 0.0;
-    for (int k = 0; k < 8; ++k) { sa += sh[k][t][0]; sb += sh[k][t][1]; }
-    sums[(sample * GN_GROUPS + t) * 2 + 0] = (float)sa;
-    sums[(sample * GN_GROUPS + t) * 2 + 1] = (float)sb;
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long sample = blockIdx.y;
+  double sa, sb;
+  gn_reduce_pair(partial, nchunks, sample, g, lane, sa, sb);
+  if (lane == 0) {
+    sums[(sample * GN_GROUPS + g) * 2 + 0] = (float)sa;
+    sums[(sample * GN_GROUPS + g) * 2 + 1] = (float)sb;
   }
 }
 __global__ void gn_finalize_sums_kernel(const float* sums, long long n, double inv_count, float eps, float* stats) {
@@ -193,7 +191,7 @@ extern "C" int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, con
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
                      nchunks);
   double inv = 1.0 / ((double)rows_per_sample * (double)((c0 + c1) / GN_GROUPS));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
                      nchunks, inv, eps, stats);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
@@ -208,7 +206,7 @@ extern "C" int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, cons
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
                      nchunks);
-  hipLaunchKernelGGL(gn_sums_kernel, dim3((unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial, nchunks,
+  hipLaunchKernelGGL(gn_sums_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial, nchunks,
                      sums);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
