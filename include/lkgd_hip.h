@@ -40,7 +40,8 @@ enum {
  *    out[m, n] = s_acc * ( sum_k A(m,k) * W[n,k] + bias[n] + rowbias[idx(m), n] )
  *                + r1 * res1[m, n] + r2 * res2[m, n]                           (fp32 accumulate, fp16 store)
  *    with idx(m) = ((m / rb_d1) * rb_m1 + (m % rb_d2) + rb_c0) % rb_md
- *    GEGLU (geglu=1): W rows are tile-interleaved [64 hidden | 64 gate]; out[m, j] = hidden * gelu_erf(gate),
+ *    GEGLU (geglu = h, h in {32, 80}): packed W rows interleave h hidden rows | their h gate rows (h = 80 selects the
+ *                     256x320-tile kernel, h = 32 the 128-wide-tile kernels); out[m, j] = hidden * gelu_erf(gate),
  *                     out has N/2 columns.
  *
  *    A(m,k) by `mode`:
@@ -61,7 +62,7 @@ enum {
  *      F.conv3d      - TemporalResnetBlock conv1/conv2 (3,1,1) [EXT resnet.py]
  *      F.gelu, residual adds, AlphaBlender - fused epilogues [EXT attention.py GEGLU, resnet.py AlphaBlender]
  *    Contract: K % 64 == 0; for conv modes Cin % 64 == 0 and csplit % 64 == 0 (C8 mode: Cin == 8, K == 128);
- *              N % 4 == 0 (geglu: N % 128 == 0); all leading dimensions % 8 == 0; pointers 16-byte aligned.
+ *              N % 4 == 0 (geglu = h: N % 4h == 0); all leading dimensions % 8 == 0; pointers 16-byte aligned.
  * ------------------------------------------------------------------------------------------------------------- */
 enum { LKGD_A_PLAIN = 0, LKGD_A_CONV3X3 = 1, LKGD_A_TCONV3 = 2, LKGD_A_CONV3X3_C8 = 3 };
 
@@ -85,7 +86,7 @@ typedef struct lkgd_gemm_desc {
   int32_t ldrb, rb_d1, rb_m1, rb_d2, rb_md, rb_c0;
   int32_t ldr1, ldr2, ldc;
   float s_acc, r1, r2;
-  int32_t geglu;
+  int32_t geglu;           /* 0 = off, 32 or 80 = GEGLU interleave width (see above) */
 } lkgd_gemm_desc;
 
 int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream);

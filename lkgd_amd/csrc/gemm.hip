@@ -238,7 +238,8 @@ static int check_desc(const lkgd_gemm_desc* d) {
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return LKGD_E_SHAPE;
   if (d->K % BK) return LKGD_E_SHAPE;
   if (d->N % 4) return LKGD_E_SHAPE;
-  if (d->geglu && (d->N % 128 || d->rowbias || d->res1 || d->res2)) return LKGD_E_SHAPE;
+  if (d->geglu != 0 && d->geglu != 32 && d->geglu != 80) return LKGD_E_MODE;
+  if (d->geglu && (d->N % (4 * d->geglu) || d->rowbias || d->res1 || d->res2)) return LKGD_E_SHAPE;
   if (d->ldc % 4 || d->lda0 % 8) return LKGD_E_ALIGN;
   if (!aligned16(d->a0) || !aligned16(d->w) || !aligned16(d->zeros) || ((uintptr_t)d->out & 7)) return LKGD_E_ALIGN;
   if (d->a1 && (!aligned16(d->a1) || d->lda1 % 8)) return LKGD_E_ALIGN;
@@ -280,9 +281,10 @@ static int check_desc(const lkgd_gemm_desc* d) {
 }
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
+extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_wide.hip
 
 // tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128 ring,
-// 3 = force the persistent streaming kernel
+// 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320)
 static int gemm_variant_override = 0;
 extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = v; }
 
@@ -298,16 +300,25 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
       return LKGD_E_LAUNCH;
     attr_set = true;
   }
-  if (gemm_variant_override == 3 || (gemm_variant_override == 0 && d->M > 256)) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LKGD_E_LAUNCH;
-      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LKGD_E_LAUNCH;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  // GEGLU weights are packed for one tile family (interleave width 80 -> 256x320 tiles, 32 -> 128-wide tiles)
+  const bool wide_ok = d->geglu == 80 || d->geglu == 0;
+  // measured per shape (profiles/r01_gemm_shapes_*.txt): the 256x320 tile wins where K is deep enough to amortise its
+  // larger epilogue and single K-tile of prefetch (3x3 / temporal convs, FF-out at 1280 channels); short-K projections
+  // stay on the 256x128 streaming kernel (three-stage ring, cheaper epilogue)
+  const bool wide_auto = d->geglu == 80 || (d->geglu == 0 && d->N % 320 == 0 && d->M >= 8192 && d->K >= 960 &&
+                                            !(d->mode == LKGD_A_PLAIN && d->K < 5120 && d->N < 1280));
+  if (d->mode != LKGD_A_CONV3X3_C8 && wide_ok &&
+      (d->geglu == 80 || gemm_variant_override == 4 || (gemm_variant_override == 0 && wide_auto)))
+    return lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus);
+  if (gemm_variant_override == 3 || gemm_variant_override == 4 || (gemm_variant_override == 0 && d->M > 256))
+    return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
   int tiles_n = (d->N + BN - 1) / BN;
   // deep-K problems (3x3 / temporal convs, K >= 960) take the 256x128 three-stage ring: its two K-tiles in flight hide
   // the HBM latency the two-stage kernel exposes every K-step.  Short-K GEMMs (K = 320/640 projections at 258k rows) are

@@ -68,7 +68,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
          mode: int = A_PLAIN, Cin: int = 0, conv: Optional[Tuple[int, int, int, int, int, int]] = None,
          tconv: Optional[Tuple[int, int]] = None, rowbias: Optional[torch.Tensor] = None,
          rowmap: Optional[RowMap] = None, res1: Optional[torch.Tensor] = None, r1: float = 1.0,
-         res2: Optional[torch.Tensor] = None, r2: float = 1.0, s_acc: float = 1.0, geglu: bool = False) -> torch.Tensor:
+         res2: Optional[torch.Tensor] = None, r2: float = 1.0, s_acc: float = 1.0, geglu: int = 0) -> torch.Tensor:
     """out = epilogue(A(.) @ w.T) - see include/lkgd_hip.h section 1.  ``conv`` = (Hout, Wout, Hin, Win, stride, ups);
     ``tconv`` = (F, HW)."""
     _req(a0, torch.float16, "a0"); _req(w, torch.float16, "w"); _req(out, torch.float16, "out")
@@ -103,7 +103,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
         d.res2, d.ldr2 = res2.data_ptr(), _ld(res2)
     d.ldc = _ld(out)
     d.s_acc, d.r1, d.r2 = s_acc, r1, r2
-    d.geglu = 1 if geglu else 0
+    d.geglu = int(geglu)        # 0 off, 32 / 80 = interleave width the weights were packed with
     ev = GEMM_EVENTS
     if ev is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

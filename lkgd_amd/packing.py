@@ -33,15 +33,25 @@ def pack_tconv3(w: torch.Tensor) -> torch.Tensor:
     return w[:, :, :, 0, 0].permute(0, 2, 1).reshape(co, 3 * ci).to(torch.float16).contiguous()
 
 
-def geglu_perm(inner: int, device=None) -> torch.Tensor:
-    """row permutation of the GEGLU projection [2*inner, K]: every 64 packed rows = 32 hidden rows followed by their 32
-    gate rows (inner + ..), so that the 64 output columns one wave owns hold both factors of 32 GEGLU outputs"""
-    assert inner % 64 == 0
-    t = torch.arange(inner // 32, device=device)[:, None] * 32 + torch.arange(32, device=device)[None, :]
+def geglu_perm(inner: int, half: int = 32, device=None) -> torch.Tensor:
+    """row permutation of the GEGLU projection [2*inner, K]: every 2*half packed rows = `half` hidden rows followed by
+    their `half` gate rows (inner + ..), so that the output columns one wave owns hold both factors of its GEGLU
+    outputs.  half = 80 for the 256x320-tile kernel (wave = 160 columns), 32 for the 128-wide-tile kernels."""
+    assert inner % half == 0
+    t = torch.arange(inner // half, device=device)[:, None] * half + torch.arange(half, device=device)[None, :]
     return torch.cat([t, t + inner], dim=1).reshape(-1)
 
 
-def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+def geglu_half(n_packed_rows: int) -> int:
+    """interleave width the kernels want for a GEGLU projection with 2*inner = n_packed_rows rows"""
+    # the wide (256x320) kernel supports an 80-wide interleave, but at the GEGLU shapes of this model (K = C <= 1280)
+    # the 256x128 streaming kernel measures faster, so 32 it is
+    return 32
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor, half: int = None):
     inner = w.shape[0] // 2
-    perm = geglu_perm(inner, w.device)
-    return w[perm].to(torch.float16).contiguous(), b[perm].to(torch.float32).contiguous()
+    if half is None:
+        half = geglu_half(w.shape[0])
+    perm = geglu_perm(inner, half, w.device)
+    return w[perm].to(torch.float16).contiguous(), b[perm].to(torch.float32).contiguous(), half

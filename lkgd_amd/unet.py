@@ -197,8 +197,9 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim_out or dim)])
 
     def pack(self):
-        wp, bp = pack_geglu(self.net[0].proj.weight.detach(), self.net[0].proj.bias.detach())
-        return SimpleNamespace(wp=wp, bp=bp, wo=pack_linear(self.net[2].weight), bo=_f32(self.net[2].bias))
+        wp, bp, half = pack_geglu(self.net[0].proj.weight.detach(), self.net[0].proj.bias.detach())
+        return SimpleNamespace(wp=wp, bp=bp, half=half, wo=pack_linear(self.net[2].weight),
+                               bo=_f32(self.net[2].bias))
 
 
 def _ff(ctx: Ctx, pk, x_norm: torch.Tensor, **epilogue) -> torch.Tensor:
@@ -206,7 +207,7 @@ def _ff(ctx: Ctx, pk, x_norm: torch.Tensor, **epilogue) -> torch.Tensor:
     T, Cc = x_norm.shape
     inner = pk.wo.shape[1]
     g = ctx.new(T, inner)
-    ops.gemm(x_norm, pk.wp, g, M=T, N=2 * inner, K=Cc, bias=pk.bp, geglu=True)
+    ops.gemm(x_norm, pk.wp, g, M=T, N=2 * inner, K=Cc, bias=pk.bp, geglu=pk.half)
     out = ctx.new(T, pk.wo.shape[0])
     ops.gemm(g, pk.wo, out, M=T, N=pk.wo.shape[0], K=inner, bias=pk.bo, **epilogue)
     return out

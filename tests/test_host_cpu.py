@@ -30,7 +30,7 @@ def test_gemm_desc_validation_without_gpu():
     from lkgd_amd import _lib
     d = _lib.GemmDesc()
     assert _lib.lib().lkgd_gemm_f16(ctypes.byref(d), None) == -1      # LKGD_E_NULL
-    assert _lib.lib().lkgd_groupnorm_chunks(129, 320) == 2
+    assert _lib.lib().lkgd_groupnorm_chunks(129, 320) == 3
 
 
 def test_scheduler_tables_equal_reference_kat():
@@ -85,9 +85,12 @@ def test_packing_layouts():
     wt = torch.randn(6, 4, 3, 1, 1, generator=g)
     p = pk.pack_tconv3(wt)
     assert torch.equal(p[3, 2 * 4 + 1], wt[3, 1, 2, 0, 0].half())
-    perm = pk.geglu_perm(128)
+    perm = pk.geglu_perm(128, 32)
     assert perm[:32].tolist() == list(range(32)) and perm[32:64].tolist() == list(range(128, 160))
     assert perm[64:96].tolist() == list(range(32, 64)) and sorted(perm.tolist()) == list(range(256))
+    perm = pk.geglu_perm(1280, 80)
+    assert perm[:80].tolist() == list(range(80)) and perm[80:160].tolist() == list(range(1280, 1360))
+    assert pk.geglu_half(2560) == 32 and pk.geglu_half(512) == 32
 
 
 def test_patch_api_bookkeeping():

@@ -24,12 +24,12 @@ def _close(got, ref, rtol=4e-3, what=""):
     assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
 
 
-@pytest.fixture(scope="module", params=["tile128", "tile256", "stream"])
+@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide"])
 def ops(request):
     """every GEMM/conv test runs against ALL kernel variants (128x128 two-stage, 256x128 three-stage ring, persistent
     streaming kernel with register epilogue)"""
     from lkgd_amd import _lib, ops
-    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3}[request.param])
+    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4}[request.param])
     yield ops
     _lib.lib().lkgd_debug_set_gemm_variant(0)
 
@@ -49,7 +49,8 @@ def test_gemm_plain_bias_residual(ops, M, N, K):
 def test_gemm_many_tiles_short_k(ops):
     """> 256 output tiles with K = 64/128 (epilogue every 1-2 K-steps), ragged M and N: stresses the streaming ring"""
     g = torch.Generator().manual_seed(77)
-    for M, N, K in ((256 * 70 + 37, 320, 64), (256 * 41 + 200, 704, 128), (256 * 300, 128, 192)):
+    for M, N, K in ((256 * 70 + 37, 320, 64), (256 * 41 + 200, 704, 128), (256 * 300, 128, 192),
+                    (256 * 33 + 5, 960, 320)):
         a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
         bias = torch.randn(N, generator=g)
         res = _h(torch.randn(M, N, generator=g))
@@ -107,10 +108,22 @@ def test_gemm_geglu(ops):
     y = a.float() @ wh.float().T + b
     hid, gate = y.chunk(2, dim=-1)
     ref = hid * F.gelu(gate)
-    wp, bp = pack_geglu(w, b)
+    wp, bp, half = pack_geglu(w, b)
+    assert half == 32
     out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
-    ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=8 * C, K=C, bias=bp.to(DEV), geglu=True)
+    ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=8 * C, K=C, bias=bp.to(DEV), geglu=half)
     _close(out, ref, what="geglu")
+    # C = 320: 8C = 2560 is a multiple of 320 -> interleave 80, always served by the 256x320-tile kernel
+    M, C = 700, 320
+    a = _h(torch.randn(M, C, generator=g))
+    w = torch.randn(8 * C, C, generator=g) / C ** 0.5
+    b = torch.randn(8 * C, generator=g) * 0.1
+    y = a.float() @ _h(w).float().T + b
+    hid, gate = y.chunk(2, dim=-1)
+    wp, bp, half = pack_geglu(w, b, half=80)
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=8 * C, K=C, bias=bp.to(DEV), geglu=half)
+    _close(out, hid * F.gelu(gate), what="geglu wide")
 
 
 def _tokens(x):  # [N,C,H,W] -> [N*H*W, C]

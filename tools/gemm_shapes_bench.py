@@ -72,8 +72,9 @@ def run(kind, d, iters=5):
         geglu = kind == "geglu"
         out = torch.empty(M, N // 2 if geglu else N, device=DEV, dtype=torch.float16)
         bias = torch.zeros(N, device=DEV)
-        res = None if geglu else torch.zeros(M, N, device=DEV, dtype=torch.float16)
-        fn = lambda: ops.gemm(a, w, out, M=M, N=N, K=K, bias=bias, geglu=geglu, res1=res)   # noqa
+        res = None if (geglu or os.environ.get('NORES')) else torch.zeros(M, N, device=DEV, dtype=torch.float16)
+        from lkgd_amd.packing import geglu_half
+        fn = lambda: ops.gemm(a, w, out, M=M, N=N, K=K, bias=bias, geglu=geglu_half(N) if geglu else 0, res1=res)   # noqa
         flop = 2.0 * M * N * K
     fn()
     torch.cuda.synchronize()
