@@ -308,6 +308,10 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   // GEGLU weights are packed for one tile family (interleave width 80 -> 256x320 tiles, 32 -> 128-wide tiles)
+  // the persistent kernels move epilogue rows as 16-byte chunks: 8-channel granularity and 16-byte aligned rows
+  const bool rows16 = d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->out) &&
+                      (!d->res1 || (d->ldr1 % 8 == 0 && aligned16(d->res1))) &&
+                      (!d->res2 || (d->ldr2 % 8 == 0 && aligned16(d->res2)));
   const bool wide_ok = d->geglu == 80 || d->geglu == 0;
   // measured per shape (profiles/r01_gemm_shapes_*.txt): the 256x320 tile wins where K is deep enough to amortise its
   // larger epilogue and single K-tile of prefetch (3x3 / temporal convs, FF-out at 1280 channels); short-K projections
@@ -317,8 +321,10 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   if (d->mode != LKGD_A_CONV3X3_C8 && wide_ok &&
       (d->geglu == 80 || gemm_variant_override == 4 || (gemm_variant_override == 0 && wide_auto)))
     return lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus);
-  if (gemm_variant_override == 3 || gemm_variant_override == 4 || (gemm_variant_override == 0 && d->M > 256))
+  if (rows16 && d->geglu != 80 &&
+      (gemm_variant_override == 3 || gemm_variant_override == 4 || (gemm_variant_override == 0 && d->M > 256)))
     return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
+  if (d->geglu == 80) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the wide kernel
   int tiles_n = (d->N + BN - 1) / BN;
   // deep-K problems (3x3 / temporal convs, K >= 960) take the 256x128 three-stage ring: its two K-tiles in flight hide
   // the HBM latency the two-stage kernel exposes every K-step.  Short-K GEMMs (K = 320/640 projections at 258k rows) are

@@ -33,6 +33,13 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + erf_s);
 }
 
+#ifdef LKGD_GEMM_STAMPS
+__device__ unsigned long long lkgd_gemm_stamps[256 * 8];
+#define STAMP(var) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; }
+#else
+#define STAMP(var)
+#endif
+
 struct TileIter {        // a workgroup's walk over its tiles
   int tile, tile_end;    // current / one-past-last linear tile id
   int tiles_n;
@@ -117,7 +124,16 @@ __global__ __launch_bounds__(SNT, 2) void lkgd_gemm_stream_kernel(const lkgd_gem
   if (total > 1) stage(1);
   int cur = 0, kt = 0, tile = tile_begin;
   bool skip_wait = false;
+  // Waves w and w+4 share a SIMD.  LDS-DMA issue is slow (~100+ cycles per instruction under load) and occupies only the
+  // issuing wave, MFMA only the matrix pipe: waves 4-7 therefore run [MFMA, then stage] while waves 0-3 run
+  // [stage, then MFMA] after the same barrier, so each SIMD always has one wave feeding the matrix pipe.
+  const bool late_stage = __builtin_amdgcn_readfirstlane(t) >= 256;
+#ifdef LKGD_GEMM_STAMPS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, a_wait = 0, a_stage = 0, a_comp = 0, a_epi = 0, t_begin = 0;
+  STAMP(t_begin)
+#endif
   for (int s = 0; s < total; ++s) {
+    STAMP(ts0)
     // K-tile s must have landed.  vmcnt is in issue order, so "at most 6 outstanding" after K-tile s+1 (6 LDS-DMA ops
     // per thread) has been issued retires K-tile s.  When the previous step ended an output tile, this wait was already
     // taken BEFORE that tile's epilogue traffic (see below).
@@ -127,10 +143,12 @@ __global__ __launch_bounds__(SNT, 2) void lkgd_gemm_stream_kernel(const lkgd_gem
     }
     skip_wait = false;
     __builtin_amdgcn_s_barrier();
-    if (s + 2 < total) {
+    STAMP(ts1)
+    if (!late_stage && s + 2 < total) {
       int nb = cur + 2; if (nb >= SNSTAGE) nb -= SNSTAGE;
       stage(nb);
     }
+    STAMP(ts2)
     const char* sbase = smem + cur * SSTAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -146,7 +164,15 @@ __global__ __launch_bounds__(SNT, 2) void lkgd_gemm_stream_kernel(const lkgd_gem
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    if (late_stage && s + 2 < total) {
+      int nb = cur + 2; if (nb >= SNSTAGE) nb -= SNSTAGE;
+      stage(nb);
+    }
     cur = cur + 1 == SNSTAGE ? 0 : cur + 1;
+    STAMP(ts3)
+#ifdef LKGD_GEMM_STAMPS
+    a_wait += ts1 - ts0; a_stage += ts2 - ts1; a_comp += ts3 - ts2;
+#endif
 
     if (++kt == nk) {
       // ------------------------------------------------------------------ epilogue of `tile`, straight from registers
@@ -160,73 +186,135 @@ __global__ __launch_bounds__(SNT, 2) void lkgd_gemm_stream_kernel(const lkgd_gem
       kt = 0;
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
       tile += nc;
+      // The ring buffer of the K-tile just consumed stays untouched until stage(s+3), which is issued after the NEXT
+      // step's barrier: once every wave is done reading it (the barrier below) it serves as per-wave transpose scratch,
+      // so that residual reads and output stores are whole 128-byte rows (8 lanes x 16 B) instead of 8-byte pieces at a
+      // 2*ldc stride (8x fewer cache-line touches per instruction).
+      __builtin_amdgcn_s_barrier();
+      char* scr = smem + (cur == 0 ? SNSTAGE - 1 : cur - 1) * SSTAGE_BYTES + w * 6144;   // 32 rows x 144 B per wave
       const int m0 = tm * SBM + wr * 64, n0 = tn * SBN + wc * 64;
       const half_t* rbp = (const half_t*)p.rowbias;
       const half_t* r1p = (const half_t*)p.res1;
       const half_t* r2p = (const half_t*)p.res2;
       half_t* outp = (half_t*)p.out;
+      const int crow = lane >> 3, cchunk = lane & 7;       // coalesced map: 8 lanes per 128-byte row, 8 rows per pass
       if (!p.geglu) {
+        const int ncol = n0 + cchunk * 8;                   // first of this lane's 8 channels in the coalesced map
+        // (1) issue EVERY epilogue load of this tile before consuming any: one exposed memory round trip per tile.
+        //     Residual rows come in coalesced (8 lanes x 16 B per row) for both token fragments.
+        uint4 rres[2][4];
+        if (r1p) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const long long mr = m0 + j * 32 + crow + 8 * it;
+              rres[j][it] = (mr < p.M && ncol < p.N) ? *(const uint4*)(r1p + mr * p.ldr1 + ncol)
+                                                     : uint4{0u, 0u, 0u, 0u};
+            }
+        }
+        // (2) bias + row-indexed bias + scale, in place in the accumulators
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const long long m = m0 + j * 32 + l31;
-          if (m < p.M) {
-            long long idx = 0;
-            if (rbp) idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
+          long long idx = 0;
+          if (rbp && m < p.M) idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int n = n0 + i * 32 + 8 * g + 4 * h;
+              float4_t v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+              if (n < p.N) {
+                if (p.bias) v += *(const float4_t*)(p.bias + n);
+                if (rbp && m < p.M) {
+                  half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + n);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
+                }
+              }
+              v *= p.s_acc;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = v[e];
+            }
+        }
+        // (3) per token fragment: residual(s) through the scratch into accumulator layout, result back out as rows
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const long long mb = m0 + j * 32;
+          if (r1p) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) *(uint4*)(scr + (crow + 8 * it) * 144 + cchunk * 16) = rres[j][it];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
-                const int n = n0 + i * 32 + 8 * g + 4 * h;
-                if (n < p.N) {
-                  float4_t v;
+                half4_t r = *(const half4_t*)(scr + l31 * 144 + (i * 32 + 8 * g + 4 * h) * 2);
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                  if (p.bias) v += *(const float4_t*)(p.bias + n);
-                  if (rbp) {
-                    half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
-                  }
-                  v *= p.s_acc;
-                  if (r1p) {
-                    half4_t r = *(const half4_t*)(r1p + m * p.ldr1 + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.r1 * (float)r[e];
-                  }
-                  if (r2p) {
-                    half4_t r = *(const half4_t*)(r2p + m * p.ldr2 + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.r2 * (float)r[e];
-                  }
-                  half4_t o;
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-                  *(half4_t*)(outp + m * p.ldc + n) = o;
-                }
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += p.r1 * (float)r[e];
               }
+          }
+          if (r2p) {   // AlphaBlender only (16 GEMMs per forward): its own round trip
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const long long mr = mb + crow + 8 * it;
+              uint4 x = {0u, 0u, 0u, 0u};
+              if (mr < p.M && ncol < p.N) x = *(const uint4*)(r2p + mr * p.ldr2 + ncol);
+              *(uint4*)(scr + (crow + 8 * it) * 144 + cchunk * 16) = x;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                half4_t r = *(const half4_t*)(scr + l31 * 144 + (i * 32 + 8 * g + 4 * h) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += p.r2 * (float)r[e];
+              }
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              half4_t o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (half_t)acc[i][j][4 * g + e];
+              *(half4_t*)(scr + l31 * 144 + (i * 32 + 8 * g + 4 * h) * 2) = o;
+            }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const long long mr = mb + crow + 8 * it;
+            const uint4 x = *(const uint4*)(scr + (crow + 8 * it) * 144 + cchunk * 16);
+            if (mr < p.M && ncol < p.N) *(uint4*)(outp + mr * p.ldc + ncol) = x;
           }
         }
       } else {
         // wave columns [0,32) = hidden, [32,64) = gate of output columns tn*64 + wc*32 + [0,32)
         const int oc0 = tn * 64 + wc * 32;
+        const int grow = lane >> 2, gchunk = lane & 3;      // 4 lanes per 64-byte row, 16 rows per pass
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const long long m = m0 + j * 32 + l31;
-          if (m < p.M) {
+          const long long mb = m0 + j * 32;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int c = 8 * g + 4 * h;
-              float4_t bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-              if (p.bias) {
-                bh = *(const float4_t*)(p.bias + n0 + c);
-                bg = *(const float4_t*)(p.bias + n0 + 32 + c);
-              }
-              half4_t o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                o[e] = (half_t)((acc[0][j][4 * g + e] + bh[e]) * gelu_fast(acc[1][j][4 * g + e] + bg[e]));
-              *(half4_t*)(outp + m * p.ldc + oc0 + c) = o;
+          for (int g = 0; g < 4; ++g) {
+            const int c = 8 * g + 4 * h;
+            float4_t bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+              bh = *(const float4_t*)(p.bias + n0 + c);
+              bg = *(const float4_t*)(p.bias + n0 + 32 + c);
             }
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              o[e] = (half_t)((acc[0][j][4 * g + e] + bh[e]) * gelu_fast(acc[1][j][4 * g + e] + bg[e]));
+            *(half4_t*)(scr + l31 * 144 + c * 2) = o;
+          }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const long long mr = mb + grow + 16 * it;
+            const uint4 x = *(const uint4*)(scr + (grow + 16 * it) * 144 + gchunk * 16);
+            if (mr < p.M) *(uint4*)(outp + mr * p.ldc + oc0 + gchunk * 8) = x;
           }
         }
       }
@@ -236,9 +324,26 @@ __global__ __launch_bounds__(SNT, 2) void lkgd_gemm_stream_kernel(const lkgd_gem
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      STAMP(ts4)
+#ifdef LKGD_GEMM_STAMPS
+      a_epi += ts4 - ts3;
+#endif
     }
   }
+#ifdef LKGD_GEMM_STAMPS
+  if (t == 0 && blockIdx.x < 256) {
+    unsigned long long t_end; STAMP(t_end)
+    unsigned long long* o = lkgd_gemm_stamps + blockIdx.x * 8;
+    o[0] = a_wait; o[1] = a_stage; o[2] = a_comp; o[3] = a_epi; o[4] = t_end - t_begin; o[5] = total;
+  }
+#endif
 }
+
+#ifdef LKGD_GEMM_STAMPS
+extern "C" int lkgd_debug_read_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lkgd_gemm_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus) {
   static bool attr_set = false;
