@@ -186,9 +186,16 @@ def main():
         tot_ms = sum(s.elapsed_time(e) for s, e, _ in events)
         tot_flop = sum(f for _, _, f in events)
         achieved = tot_flop / (tot_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_kernel", "achieved": round(achieved, 2),
+        traffic = None      # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMC itself)
+        try:
+            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["gemm_family_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_{stream,wide}_kernel (MFMA GEMM / implicit-conv family)",
+                    "achieved": round(achieved, 2),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches": len(events),
+                    "traffic": traffic, "launches": len(events),
                     "avg_launch_us": round(tot_ms * 1e3 / len(events), 2),
                     "gemm_share_of_wall": round(tot_ms * 1e-3 / dt, 3)}
 

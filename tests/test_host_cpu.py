@@ -30,7 +30,7 @@ def test_gemm_desc_validation_without_gpu():
     from lkgd_amd import _lib
     d = _lib.GemmDesc()
     assert _lib.lib().lkgd_gemm_f16(ctypes.byref(d), None) == -1      # LKGD_E_NULL
-    assert _lib.lib().lkgd_groupnorm_chunks(129, 320) == 3
+    assert _lib.lib().lkgd_groupnorm_chunks(129, 320) == 3 and _lib.lib().lkgd_groupnorm_chunks(576, 1280) == 48
 
 
 def test_scheduler_tables_equal_reference_kat():

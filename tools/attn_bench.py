@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Spatial / temporal attention kernel throughput at the C2 shapes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from lkgd_amd import ops
+
+DEV = "cuda:0"
+
+
+def bench(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+tot_ms = tot_f = 0.0
+for (nb, heads, S, layers) in ((28, 5, 9216, 5), (28, 10, 2304, 5), (28, 20, 576, 5), (28, 20, 144, 1)):
+    C = heads * 64
+    qkv = torch.randn(nb * S, 3 * C, device=DEV, dtype=torch.float16)
+    out = torch.empty(nb * S, C, device=DEV, dtype=torch.float16)
+    ms = bench(lambda: ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, nb, S, heads))
+    fl = 4.0 * S * S * 64 * heads * nb
+    print(f"spatial S={S:5d} heads={heads:2d}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  (x{layers})")
+    tot_ms += ms * layers
+    tot_f += fl * layers
+print(f"spatial total per forward: {tot_ms:.2f} ms, {tot_f/tot_ms/1e9:.1f} TFLOP/s")
+for (B, F, S, heads, layers) in ((2, 14, 9216, 5, 5), (2, 14, 2304, 10, 5), (2, 14, 576, 20, 5), (2, 14, 144, 20, 1)):
+    C = heads * 64
+    qkv = torch.randn(B * F * S, 3 * C, device=DEV, dtype=torch.float16)
+    out = torch.empty(B * F * S, C, device=DEV, dtype=torch.float16)
+    ms = bench(lambda: ops.attn_temporal(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, B, F, S, heads))
+    gb = B * F * S * C * 2 * 4 / 1e9
+    print(f"temporal S={S:5d} heads={heads:2d}: {ms:7.3f} ms  {gb/ms*1e3:7.1f} GB/s (x{layers})")
