@@ -282,9 +282,11 @@ static int check_desc(const lkgd_gemm_desc* d) {
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_wide.hip
+extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
 
 // tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128 ring,
-// 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320)
+// 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320),
+// 5 = force the register-resident row-panel kernel where it applies (plain A, K <= 320)
 static int gemm_variant_override = 0;
 extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = v; }
 
@@ -312,6 +314,10 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   const bool rows16 = d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->out) &&
                       (!d->res1 || (d->ldr1 % 8 == 0 && aligned16(d->res1))) &&
                       (!d->res2 || (d->ldr2 % 8 == 0 && aligned16(d->res2)));
+  // short-K projections: token panel in registers, weights streamed (gemm_rowpanel.hip)
+  const bool rp_ok = rows16 && d->mode == LKGD_A_PLAIN && d->K <= 320 && d->csplit >= d->K && d->geglu != 80;
+  if (rp_ok && (gemm_variant_override == 5 || (gemm_variant_override == 0 && d->M >= 4096 && d->K >= 192)))
+    return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
   const bool wide_ok = d->geglu == 80 || d->geglu == 0;
   // measured per shape (profiles/r01_gemm_shapes_*.txt): the 256x320 tile wins where K is deep enough to amortise its
   // larger epilogue and single K-tile of prefetch (3x3 / temporal convs, FF-out at 1280 channels); short-K projections

@@ -24,12 +24,12 @@ def _close(got, ref, rtol=4e-3, what=""):
     assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
 
 
-@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide"])
+@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel"])
 def ops(request):
     """every GEMM/conv test runs against ALL kernel variants (128x128 two-stage, 256x128 three-stage ring, persistent
     streaming kernel with register epilogue)"""
     from lkgd_amd import _lib, ops
-    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4}[request.param])
+    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5}[request.param])
     yield ops
     _lib.lib().lkgd_debug_set_gemm_variant(0)
 
@@ -61,6 +61,22 @@ def test_gemm_many_tiles_short_k(ops):
         out2 = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
         ops.gemm(a.to(DEV), w.to(DEV), out2, M=M, N=N, K=K)       # no epilogue loads at all
         _close(out2, a.float() @ w.float().T, what="gemm many tiles, bare")
+
+
+def test_gemm_rowpanel_shapes(ops):
+    """the short-K projection shapes (K = 64..320, several panels per workgroup, ragged M/N, residual + row bias + blend)"""
+    g = torch.Generator().manual_seed(55)
+    for M, N, K in ((256 * 300 + 77, 320, 320), (256 * 9 + 1, 960, 320), (4100, 200, 256), (70000, 64, 64)):
+        a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+        bias = torch.randn(N, generator=g)
+        r1, r2 = _h(torch.randn(M, N, generator=g)), _h(torch.randn(M, N, generator=g))
+        table = _h(torch.randn(7, N, generator=g))
+        idx = (torch.arange(M) // 100) % 7
+        ref = 0.7 * (a.float() @ w.float().T + bias + table.float()[idx]) + 0.7 * r1.float() + 0.3 * r2.float()
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+        ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=bias.to(DEV), rowbias=table.to(DEV),
+                 rowmap=ops.rowmap_div_mod(100, 7), s_acc=0.7, res1=r1.to(DEV), r1=0.7, res2=r2.to(DEV), r2=0.3)
+        _close(out, ref, what=f"rowpanel-class gemm {M}x{N}x{K}")
 
 
 def test_gemm_two_source_and_blend(ops):
@@ -120,6 +136,14 @@ def test_gemm_geglu(ops):
     b = torch.randn(8 * C, generator=g) * 0.1
     y = a.float() @ _h(w).float().T + b
     hid, gate = y.chunk(2, dim=-1)
+    wp32, bp32, _ = pack_geglu(w, b, half=32)
+    M2 = 256 * 20 + 9
+    a2 = _h(torch.randn(M2, C, generator=g))
+    y2 = a2.float() @ _h(w).float().T + b
+    h2, g2 = y2.chunk(2, dim=-1)
+    out2 = torch.empty(M2, 4 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(a2.to(DEV), wp32.to(DEV), out2, M=M2, N=8 * C, K=C, bias=bp32.to(DEV), geglu=32)
+    _close(out2, h2 * F.gelu(g2), what="geglu K=320 (row-panel class)")
     wp, bp, half = pack_geglu(w, b, half=80)
     out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
     ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=8 * C, K=C, bias=bp.to(DEV), geglu=half)

@@ -14,7 +14,7 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "liblkgd_hip_dbg.so
 from lkgd_amd import ops   # noqa: E402
 
 L = _lib.lib()
-L.lkgd_debug_set_gemm_variant(3)
+L.lkgd_debug_set_gemm_variant(int(os.environ.get("VARIANT", "3")))
 DEV = "cuda:0"
 
 
@@ -31,7 +31,7 @@ def run(name, M, N, K, res=False, geglu=0):
     assert L.lkgd_debug_read_stamps(buf) == 0
     t = torch.tensor(list(buf), dtype=torch.float64).reshape(256, 8)
     wait, stage, comp, epi, tot, steps = (t[:, i].mean().item() for i in range(6))
-    nk = K // 64
+    nk = K // 64 if os.environ.get("VARIANT", "3") != "5" else 1
     print(f"{name:28s} steps/blk {steps:6.0f} tiles/blk {steps/nk:5.1f} | per K-step: wait {wait/steps:6.0f} stage {stage/steps:5.0f} "
           f"mfma {comp/steps:6.0f} | epilogue/tile {epi/(steps/nk):7.0f} | total {tot:9.0f} cyc "
           f"= wait {100*wait/tot:4.1f}% stage {100*stage/tot:4.1f}% mfma {100*comp/tot:4.1f}% epi {100*epi/tot:4.1f}%")
