@@ -212,7 +212,8 @@ def attn_temporal(q, k, v, out, B: int, F: int, S: int, heads: int, kv_b_map: Op
     return out
 
 
-def prepare_unet_input(latents: torch.Tensor, image_latents: torch.Tensor, cfg: int, sigma: float) -> torch.Tensor:
+def prepare_unet_input(latents: torch.Tensor, image_latents: torch.Tensor, cfg: int, sigma: float,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[B,F,4,H,W] latents (+ [cfg*B,F,4,H,W] image latents) -> channels-last tokens [cfg*B*F*H*W, 8]"""
     B, F, _, H, W = latents.shape
     _req(image_latents, torch.float16, "image_latents")
@@ -220,7 +221,8 @@ def prepare_unet_input(latents: torch.Tensor, image_latents: torch.Tensor, cfg: 
         raise _lib.LkgdHipError("latents must be a GPU fp16/fp32 tensor")
     assert latents.is_contiguous() and image_latents.is_contiguous()
     assert image_latents.shape == (cfg * B, F, 4, H, W), image_latents.shape
-    out = torch.empty(cfg * B * F * H * W, 8, dtype=torch.float16, device=latents.device)
+    if out is None:
+        out = torch.empty(cfg * B * F * H * W, 8, dtype=torch.float16, device=latents.device)
     check(_lib.lib().lkgd_prepare_unet_input(latents.data_ptr(), int(latents.dtype == torch.float32),
                                              image_latents.data_ptr(), B, F, H, W, cfg, sigma, out.data_ptr(),
                                              _stream()), "lkgd_prepare_unet_input")

@@ -48,6 +48,11 @@ class StableVideoDiffusionPipeline:
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
         self._guidance_scale = None
         self._num_timesteps = 0
+        #: replay the per-step UNet forward from a captured HIP graph (one launch instead of ~1000): the forward is
+        #: shape-static across the Euler steps, only the timestep scalar and the input tokens change (static buffers)
+        self.use_hip_graph = False   # opt-in: eager launches are already hidden behind GPU work on one GPU, and bench.py times
+                                     # individual GEMM launches with events, which a graph replay cannot expose
+        self._graph = None
 
     # ---- reference helpers -------------------------------------------------------------------------------------
     @property
@@ -174,11 +179,16 @@ class StableVideoDiffusionPipeline:
         ids = added_time_ids.to(dev)
         vpred = sch.config.prediction_type == "v_prediction"
         from . import patch as _patch
+        _patch.set_joint_attention(unet, enable=True)           # reference :555 (no-op unless the model is patched)
+        fwd = self._graphed_forward(cfg * B, F, H, W, enc, ids) if self.use_hip_graph else None
         for i, t in enumerate(sch.timesteps_host):
             sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
-            tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)
-            _patch.set_joint_attention(unet, enable=True)       # reference :555 (no-op unless the model is patched)
-            noise_tok, _ = unet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids)
+            if fwd is not None:
+                ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=fwd.tok)
+                noise_tok = fwd.run(t)
+            else:
+                tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)
+                noise_tok, _ = unet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids)
             ops.cfg_euler_step(noise_tok, latents, guidance_dev, cfg, sigma, sigma_next, v_prediction=vpred)
             if callback_on_step_end is not None:
                 kw = {k: {"latents": latents}[k] for k in callback_on_step_end_tensor_inputs}
@@ -186,6 +196,44 @@ class StableVideoDiffusionPipeline:
                 latents = out.pop("latents", latents) if isinstance(out, dict) else latents
         sch._step_index = num_inference_steps
         return latents
+
+    def _graphed_forward(self, Bc: int, F: int, H: int, W: int, enc: torch.Tensor, ids: torch.Tensor):
+        """HIP-graph replay of ``unet.forward_tokens`` for fixed shapes / conditioning.  Static buffers: input tokens,
+        timestep scalar; the captured kernels are exactly the ones the eager path launches (same stream semantics:
+        everything in lkgd_amd/csrc is capturable - no allocation or sync inside).  Re-captured when shapes, weights or
+        the conditioning tensors change."""
+        unet = self.unet
+        key = (Bc, F, H, W, enc.data_ptr(), enc._version, ids.data_ptr(), ids._version, id(unet._pk),
+               getattr(unet, "_joint_attn_mask", None) is not None)
+        g = self._graph
+        if g is not None and g.key == key:
+            return g
+        dev = unet.device
+
+        class _G:
+            pass
+        g = _G()
+        g.key = key
+        g.tok = torch.empty(Bc * F * H * W, 8, dtype=torch.float16, device=dev)
+        g.t = torch.zeros(1, dtype=torch.float32, device=dev)
+        g.tok.zero_()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                    # warm-up on a side stream (allocator pools, lazy caches)
+            unet.forward_tokens(g.tok, Bc, F, H, W, g.t, enc, ids)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g.out, _ = unet.forward_tokens(g.tok, Bc, F, H, W, g.t, enc, ids)
+        g.graph = graph
+
+        def run(t_value: float, _g=g):
+            _g.t.fill_(float(t_value))
+            _g.graph.replay()
+            return _g.out
+        g.run = run
+        self._graph = g
+        return g
 
     @torch.no_grad()
     def __call__(self, image, height: int = 576, width: int = 1024, num_frames: Optional[int] = None,

@@ -10,6 +10,7 @@ name-only stubs by tests/golden/make_goldens.py) on the blocks of oracle/blocks.
 from __future__ import annotations
 
 import copy
+import math
 
 import torch
 import torch.nn as nn
@@ -98,3 +99,57 @@ def temporal_block_forward(block: TemporalBasicTransformerBlock, hidden_states, 
     ff = block.ff(block.norm3(h))
     h = ff + h if block.is_res else ff
     return h[None, :].reshape(b, s, num_frames, c).permute(0, 2, 1, 3).reshape(b * num_frames, s, c)
+
+
+# ------------------------------------------------------------------------------------------------ FSM hook (a15)
+def initialize_fsm_layers(block: nn.Module) -> None:
+    """patch_FSM.py:92-97: zero-initialised 3x3 ``conv_fuse`` on 2C channels"""
+    c = block.attn1.out_dim
+    block.conv_fuse = nn.Conv2d(2 * c, 2 * c, 3, 1, 1)
+    nn.init.zeros_(block.conv_fuse.weight)
+    nn.init.zeros_(block.conv_fuse.bias)
+
+
+def fsm_block_forward(block: BasicTransformerBlock, hidden_states, encoder_hidden_states, track, track_res,
+                      enable=True):
+    """/root/reference/patch/patch_FSM.py ``ToMeBlock.forward`` :312-504 for norm_type == "layer_norm": self-attention,
+    then the track-guided fuse :380-441 between even (src) and odd (dst) batch entries, then cross-attention and FF.
+    ``track`` = (src_tracks [B/2,P,2] (x,y), dst_tracks, pred_visibility [B/2,P]); ``track_res`` = (..., H, W)."""
+    n = block.norm1(hidden_states)
+    hidden_states = block.attn1(n) + hidden_states
+    if enable:
+        track_h, track_w = track_res[-2:]
+        downsample = int(math.ceil(math.sqrt((track_h * track_w) // hidden_states.shape[1])))
+        feat_h, feat_w = track_h // downsample, track_w // downsample
+        src_tracks, dst_tracks, vis = track
+        src_tracks = (src_tracks / downsample).long()
+        dst_tracks = (dst_tracks / downsample).long()
+        dst_tracks[..., 0] = dst_tracks[..., 0].clamp(0, feat_w - 1)
+        dst_tracks[..., 1] = dst_tracks[..., 1].clamp(0, feat_h - 1)
+        src_idx = src_tracks[..., 0] + src_tracks[..., 1] * feat_w
+        dst_idx = dst_tracks[..., 0] + dst_tracks[..., 1] * feat_w
+        src_feats, dst_feats = hidden_states[::2], hidden_states[1::2]
+        B, N, C = src_feats.shape
+        visx = vis.unsqueeze(-1).expand(B, -1, C)
+        invisible = visx == 0
+        visf = visx.to(src_feats)
+        gathered = torch.gather(dst_feats, 1, dst_idx.unsqueeze(-1).expand(B, -1, C)).clone()
+        gathered[invisible] = 0
+        canvas = torch.zeros_like(src_feats)
+        scat = torch.scatter_add(canvas, 1, src_idx.unsqueeze(-1).expand(B, -1, C), gathered)
+        cnt = torch.scatter_add(canvas, 1, src_idx.unsqueeze(-1).expand(B, -1, C), visf)
+        reduced_src = scat / (cnt + 1e-6)
+        cat = torch.cat([src_feats, reduced_src], dim=-1)
+        cat = cat.reshape(B, feat_h, feat_w, 2 * C).permute(0, 3, 1, 2)
+        fused = block.conv_fuse(cat).permute(0, 2, 3, 1).reshape(B, N, 2 * C)
+        src_fused, sdst_fused = fused.chunk(2, dim=-1)
+        regathered = torch.gather(sdst_fused, 1, src_idx.unsqueeze(-1).expand(B, -1, C)).clone()
+        regathered[invisible] = 0
+        canvas = torch.zeros_like(dst_feats)
+        dfused = torch.scatter_add(canvas, 1, dst_idx.unsqueeze(-1).expand(B, -1, C), regathered)
+        cntd = torch.scatter_add(canvas, 1, dst_idx.unsqueeze(-1).expand(B, -1, C), visf)
+        reduced_dst = dfused / (cntd + 1e-6)
+        fused2 = torch.stack([src_fused, reduced_dst], dim=1).reshape(2 * B, N, C)
+        hidden_states = hidden_states + fused2
+    hidden_states = block.attn2(block.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states) + hidden_states
+    return block.ff(block.norm3(hidden_states)) + hidden_states

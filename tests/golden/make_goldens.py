@@ -12,6 +12,7 @@ therefore everything the reference itself implements on the path:
                              and without ControlNet residuals) and models/unet_spatio_temporal_condition.py
                              ``forward`` (LK signature incl. the latent-knowledge fuse), tiny config
 * patch_joint.safetensors <- patch/patch.py ``apply_patch`` + ``ToMeBlock.forward`` / ``forward_temporal`` joint branch
+* patch_fsm.safetensors   <- patch/patch_FSM.py ``apply_patch`` + ``ToMeBlock.forward`` FSM branch (:380-441)
 * loop.safetensors        <- pipeline/pipeline_stable_video_diffusion_trans.py ``__call__`` (output_type="latent")
                              with stand-in CLIP/VAE stages (boundary stages, outside the hot path)
 
@@ -369,6 +370,46 @@ def gen_patch(patch_mod):
     print("patch: joint vs nojoint delta %.4f" % (out["spatial_joint_noflip"] - out["spatial_nojoint"]).abs().max())
 
 
+def gen_patch_fsm(fsm_mod):
+    torch.manual_seed(51)
+    holder = _Holder()
+    ou.init_weights_(holder, 51)
+    holder.__class__ = type("Holder", (_Holder, sys.modules["diffusers.models.modeling_utils"].ModelMixin), {})
+    C, fh, fw = 128, 6, 8
+    S = fh * fw
+    nb, P = 6, 40                      # 3 (src, dst) pairs, 40 tracked points each
+    g = torch.Generator().manual_seed(52)
+    x = torch.randn(nb, S, C, generator=g)
+    enc = torch.randn(nb, 1, 1024, generator=g)
+    track_res = (2 * fh, 2 * fw)       # tracks live on a 2x finer grid -> downsample 2
+    src = torch.stack([torch.randint(0, 2 * fw, (nb // 2, P), generator=g),
+                       torch.randint(0, 2 * fh, (nb // 2, P), generator=g)], dim=-1).float()
+    dst = torch.stack([torch.randint(-3, 2 * fw + 3, (nb // 2, P), generator=g),      # dst may leave the image: clamped
+                       torch.randint(-3, 2 * fh + 3, (nb // 2, P), generator=g)], dim=-1).float()
+    vis = (torch.rand(nb // 2, P, generator=g) > 0.25).float()
+    out = {"in_x": x, "in_enc": enc, "src_tracks": src, "dst_tracks": dst, "vis": vis,
+           "track_res": torch.tensor(track_res)}
+    with torch.no_grad():
+        fsm_mod.apply_patch(holder, with_spatial_block=True, with_temporal_block=False)
+        fsm_mod.initialize_joint_layers(holder)
+        fsm_mod.update_patch(holder, track=(src.clone(), dst.clone(), vis.clone()), track_res=track_res)
+        fsm_mod.set_joint_attention(holder, True)
+        out["fsm_zero_init"] = holder.spatial(x, encoder_hidden_states=enc)          # zero conv_fuse => identity
+        gg = torch.Generator().manual_seed(53)
+        holder.spatial.conv_fuse.weight.copy_(torch.randn(2 * C, 2 * C, 3, 3, generator=gg) / (18 * C) ** 0.5)
+        holder.spatial.conv_fuse.bias.copy_(0.1 * torch.randn(2 * C, generator=gg))
+        out["conv_fuse_w"] = holder.spatial.conv_fuse.weight.clone()
+        out["conv_fuse_b"] = holder.spatial.conv_fuse.bias.clone()
+        fsm_mod.update_patch(holder, track=(src.clone(), dst.clone(), vis.clone()), track_res=track_res)
+        out["fsm_on"] = holder.spatial(x, encoder_hidden_states=enc)
+        fsm_mod.set_joint_attention(holder, False)
+        out["fsm_off"] = holder.spatial(x, encoder_hidden_states=enc)
+        fsm_mod.remove_patch(holder)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "patch_fsm.safetensors"))
+    print("patch_FSM: on vs off delta %.4f, zero-init delta %.2e" % (
+        (out["fsm_on"] - out["fsm_off"]).abs().max(), (out["fsm_zero_init"] - out["fsm_off"]).abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------ 4. pipeline loop
 class _FakeVAE(nn.Module):
     """Boundary stand-in: 8x average pool + fixed channel mix -> 4 latent channels."""
@@ -447,7 +488,16 @@ def main():
     patch_mod = load_ref("patch/patch.py", "patch.patch")
     sys.modules["patch"].patch = patch_mod
     gen_patch(patch_mod)
-    _mod("models"); _mod("utils")
+    uo = _mod("utils.optical_flow") if "utils" in sys.modules else None
+    if uo is None:
+        _mod("utils")
+        uo = _mod("utils.optical_flow")
+    uo.warp_frames = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("name-only stub"))   # imported, never called
+    fsm_mod = load_ref("patch/patch_FSM.py", "patch.patch_FSM")
+    gen_patch_fsm(fsm_mod)
+    _mod("models")
+    if "utils" not in sys.modules:
+        _mod("utils")
     sys.modules["models.unet_spatio_temporal_condition_controlnet"] = ref_stock
     sys.modules["utils.scheduling_euler_discrete_karras_fix"] = sched_mod
     pipe_mod = load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans")

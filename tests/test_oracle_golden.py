@@ -153,6 +153,28 @@ def test_patch_joint_hooks(golden_dir):
         torch.testing.assert_close(h.temporal(x, 3, tctx), g["temporal_nojoint"], rtol=1e-5, atol=1e-5)
 
 
+def test_patch_fsm_hook(golden_dir):
+    """a15: track-guided fuse of patch/patch_FSM.py:380-441 against the reference's own ToMeBlock output"""
+    g = load_file(os.path.join(golden_dir, "patch_fsm.safetensors"))
+    torch.manual_seed(51)
+    h = ou.init_weights_(_Holder(), 51)
+    track = (g["src_tracks"], g["dst_tracks"], g["vis"])
+    res = tuple(int(v) for v in g["track_res"])
+    x, enc = g["in_x"], g["in_enc"]
+    with torch.no_grad():
+        oph.initialize_fsm_layers(h.spatial)
+        y = oph.fsm_block_forward(h.spatial, x, enc, track, res)
+        torch.testing.assert_close(y, g["fsm_zero_init"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(y, g["fsm_off"], rtol=1e-5, atol=1e-5)
+        h.spatial.conv_fuse.weight.copy_(g["conv_fuse_w"])
+        h.spatial.conv_fuse.bias.copy_(g["conv_fuse_b"])
+        y = oph.fsm_block_forward(h.spatial, x, enc, track, res)
+        torch.testing.assert_close(y, g["fsm_on"], rtol=1e-5, atol=1e-5)
+        assert (g["fsm_on"] - g["fsm_off"]).abs().max() > 0.5
+        y = oph.fsm_block_forward(h.spatial, x, enc, track, res, enable=False)
+        torch.testing.assert_close(y, g["fsm_off"], rtol=1e-5, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------ loop (a1)
 def test_loop_against_reference_pipeline(golden_dir):
     g = load_file(os.path.join(golden_dir, "loop.safetensors"))

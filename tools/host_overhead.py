@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""How long does the HOST take to enqueue one UNet forward (Python + ctypes launches) vs the GPU to execute it?"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench as B
+from lkgd_amd import ops
+
+dev = torch.device("cuda", 0)
+unet = B.build_unet(dev, False)
+for (frames, h, w, tag) in ((2, 8, 8, "2 frames 8x8 (launch-bound)"), (14, 72, 128, "C2 full"), (4, 72, 128, "4 frames (8-GPU slice)")):
+    lat0, img, emb, ids = B.synthetic_inputs(dev, frames, h, w)
+    cfgb = 2
+    tok = ops.prepare_unet_input(lat0.half(), img, 2, 700.0)
+    for _ in range(2):
+        unet.forward_tokens(tok, cfgb, frames, h, w, 1.0, emb, ids)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        unet.forward_tokens(tok, cfgb, frames, h, w, 1.0, emb, ids)
+    t_host = (time.perf_counter() - t0) / n
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / n
+    print(f"{tag:26s}: host enqueue {t_host*1e3:7.1f} ms / forward, end-to-end {t_all*1e3:7.1f} ms / forward")
