@@ -189,6 +189,35 @@ int lkgd_scale(const void* x, void* y, int64_t n, float s, lkgd_stream_t stream)
 int lkgd_euler_step(const void* model_output, const void* sample, int32_t sample_is_f32, void* prev, int64_t n,
                     float sigma, float sigma_next, int32_t prediction_type, lkgd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * 9. FSM hook row kernel (patch/patch_FSM.py:380-441, the track-guided fuse between even "src" and odd "dst" batch
+ *    entries).  Token rows are addressed per PAIR of entries:
+ *        row_x(pair, cell) = pair * x_pair_rows + x_off + cell,   cell in [0, HW)
+ *    out[row_o] = value + res[row_r] + bias[(pair * bias_mul + bias_add) / bias_div]           (res, bias optional)
+ *    value = a[row_a(pair, cell)]                                             when csr_off == NULL  (copy / combine)
+ *    value = fp16( sum_{i in [csr_off[pair*HW+cell], csr_off[pair*HW+cell+1])}  vis[p] != 0 ? a[row_a(pair, gather_idx[p])] : 0
+ *                  / (sum_i vis[p] + 1e-6) ),  p = csr_pt[i]                    otherwise
+ *    which is torch.gather + masked zero + scatter_add + count-normalise of :405-418 / :429-437 with the tracks inverted
+ *    on the host: csr_pt lists, per target cell, the global point ids (pair * P + k) in increasing order, so the fp32
+ *    sum runs in the order of a sequential scatter_add; gather_idx / vis are indexed by global point id.
+ *    All feature pointers fp16 with leading dimensions in elements (multiples of 8), C % 8 == 0, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct lkgd_fsm_desc {
+  const void* a;
+  const void* res;
+  const void* bias;
+  void* out;
+  const int32_t* csr_off;    /* [pairs*HW + 1] or NULL */
+  const int32_t* csr_pt;     /* [pairs*P] */
+  const int32_t* gather_idx; /* [pairs*P] source cell of each point */
+  const float* vis;          /* [pairs*P] visibility (0 = masked, value is the count weight) */
+  int64_t a_pair_rows, a_off, r_pair_rows, r_off, o_pair_rows, o_off;
+  int32_t lda, ldr, ldb, ldo;
+  int32_t bias_mul, bias_add, bias_div;
+  int32_t pairs, HW, C, P;
+} lkgd_fsm_desc;
+int lkgd_fsm_rows(const lkgd_fsm_desc* desc, lkgd_stream_t stream);
+
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
 

@@ -39,6 +39,19 @@ class GemmDesc(C.Structure):
 
 #: every symbol include/lkgd_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+class FsmDesc(C.Structure):
+    """struct lkgd_fsm_desc (include/lkgd_hip.h section 9)."""
+    _fields_ = [
+        ("a", C.c_void_p), ("res", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+        ("csr_off", C.c_void_p), ("csr_pt", C.c_void_p), ("gather_idx", C.c_void_p), ("vis", C.c_void_p),
+        ("a_pair_rows", C.c_int64), ("a_off", C.c_int64), ("r_pair_rows", C.c_int64), ("r_off", C.c_int64),
+        ("o_pair_rows", C.c_int64), ("o_off", C.c_int64),
+        ("lda", C.c_int32), ("ldr", C.c_int32), ("ldb", C.c_int32), ("ldo", C.c_int32),
+        ("bias_mul", C.c_int32), ("bias_add", C.c_int32), ("bias_div", C.c_int32),
+        ("pairs", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("P", C.c_int32),
+    ]
+
+
 SYMBOLS = {
     "lkgd_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "lkgd_groupnorm_chunks": (_i32, [_i64, _i32]),
@@ -61,6 +74,7 @@ SYMBOLS = {
     "lkgd_add": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "lkgd_scale": (_i32, [_vp, _vp, _i64, _f32, _vp]),
     "lkgd_euler_step": (_i32, [_vp, _vp, _i32, _vp, _i64, _f32, _f32, _i32, _vp]),
+    "lkgd_fsm_rows": (_i32, [C.POINTER(FsmDesc), _vp]),
     "lkgd_version": (C.c_char_p, []),
 }
 

@@ -282,6 +282,40 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def fsm_rows(a: torch.Tensor, out: torch.Tensor, *, pairs: int, HW: int, C_: int, a_rows: Tuple[int, int],
+             o_rows: Tuple[int, int], res: Optional[torch.Tensor] = None, r_rows: Tuple[int, int] = (0, 0),
+             bias: Optional[torch.Tensor] = None, bias_map: Tuple[int, int, int] = (1, 0, 1),
+             csr: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """FSM hook row kernel (include/lkgd_hip.h section 9).  ``x_rows`` = (rows per pair, row offset); ``csr`` =
+    (csr_off int32 [pairs*HW+1], csr_pt int32 [pairs*P], gather_idx int32 [pairs*P], vis fp32 [pairs*P])."""
+    _req(a, torch.float16, "a"); _req(out, torch.float16, "out")
+    d = _lib.FsmDesc()
+    d.a, d.out, d.lda, d.ldo = a.data_ptr(), out.data_ptr(), _ld(a), _ld(out)
+    d.a_pair_rows, d.a_off = a_rows
+    d.o_pair_rows, d.o_off = o_rows
+    d.pairs, d.HW, d.C = pairs, HW, C_
+    if res is not None:
+        _req(res, torch.float16, "res")
+        d.res, d.ldr = res.data_ptr(), _ld(res)
+        d.r_pair_rows, d.r_off = r_rows
+    if bias is not None:
+        _req(bias, torch.float16, "bias")
+        d.bias, d.ldb = bias.data_ptr(), _ld(bias)
+        d.bias_mul, d.bias_add, d.bias_div = bias_map
+    if csr is not None:
+        off, pt, gi, vis = csr
+        for t, dt, n in ((off, torch.int32, "csr_off"), (pt, torch.int32, "csr_pt"), (gi, torch.int32, "gather_idx"),
+                         (vis, torch.float32, "vis")):
+            if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                raise _lib.LkgdHipError(f"{n} must be a contiguous GPU {dt} tensor")
+        if off.numel() != pairs * HW + 1 or pt.numel() != gi.numel() or pt.numel() != vis.numel():
+            raise _lib.LkgdHipError("fsm_rows: CSR table sizes do not match pairs*HW / pairs*P")
+        d.csr_off, d.csr_pt, d.gather_idx, d.vis = off.data_ptr(), pt.data_ptr(), gi.data_ptr(), vis.data_ptr()
+        d.P = pt.numel() // pairs
+    check(_lib.lib().lkgd_fsm_rows(C.byref(d), _stream()), "lkgd_fsm_rows")
+    return out
+
+
 def scale(x: torch.Tensor, s: float) -> torch.Tensor:
     _req(x, torch.float16, "x")
     x = x.contiguous()

@@ -256,6 +256,8 @@ class BasicTransformerBlock(nn.Module):
         if hasattr(self, "attn1n"):
             pk.a1n = self.attn1n.pack_self(self.norm1)
             pk.conv1n = pack_linear(self.conv1n.weight) if hasattr(self, "conv1n") else None
+        if hasattr(self, "conv_fuse"):      # FSM hook (lkgd_amd/patch_FSM.py)
+            pk.wfuse, pk.bfuse = pack_conv3x3(self.conv_fuse.weight), _f32(self.conv_fuse.bias)
         self._pk = pk
 
     def run(self, ctx: Ctx, h: torch.Tensor) -> torch.Tensor:
@@ -267,6 +269,12 @@ class BasicTransformerBlock(nn.Module):
         att = ctx.new(T, Cc)
         ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, heads)
         h1 = ctx.new(T, Cc)
+        if getattr(self, "_lkgd_fsm", False) and self.enable_joint_attention:
+            # the track fuse reads attn1(x) + x BEFORE cross-attention: the folded attn2 bias is added by its last kernels
+            ops.gemm(att, pk.a1.wo, h1, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=h)
+            h1 = self._fsm(ctx, h1)
+            ln3 = ops.layernorm(h1, None, None, 1e-5)
+            return _ff(ctx, pk.ff, ln3, res1=h1)
         # attn1 out-projection + residual + (attn2 == per-batch bias, norm2/Q/K are dead for one key token)
         ops.gemm(att, pk.a1.wo, h1, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=h,
                  rowbias=ctx.xb_all[ctx.b0:, pk.xoff:pk.xoff + Cc], rowmap=ops.rowmap_div(ctx.F * ctx.HW))
@@ -291,6 +299,35 @@ class BasicTransformerBlock(nn.Module):
         ops.gemm(att, pk.a1n.wo, o1n, M=T, N=Cc, K=Cc, bias=pk.a1n.bo)
         out = ctx.new(T, Cc)
         ops.gemm(o1n, pk.conv1n, out, M=T, N=Cc, K=Cc, s_acc=float(self.joint_scale), res1=h1)
+        return out
+
+
+    def _fsm(self, ctx: Ctx, hA: torch.Tensor) -> torch.Tensor:
+        """track-guided fuse between even (src) and odd (dst) batch entries (patch/patch_FSM.py:380-441): gather dst
+        tokens at the tracked points, scatter-mean onto the src grid, 3x3 ``conv_fuse`` over cat(src, reduced), scatter
+        the fused partner half back along the tracks; returns hA + fused + cross-attention bias."""
+        pk, T, Cc = self._pk, hA.shape[0], hA.shape[1]
+        if not hasattr(pk, "wfuse"):
+            raise LkgdHipError("FSM hook enabled but conv_fuse is missing (patch_FSM.initialize_joint_layers)")
+        if ctx.shard is not None:
+            raise LkgdHipError("the FSM hook pairs neighbouring batch entries and is not available under sharding")
+        if ctx.N % 2:
+            raise LkgdHipError("FSM hook: batch*frames must be even (hidden_states[::2] / [1::2] pairs)")
+        from .patch_FSM import track_tables
+        fwd, bwd = track_tables(self, ctx)
+        pairs, HW = ctx.N // 2, ctx.HW
+        srcf, red = ctx.new(pairs * HW, Cc), ctx.new(pairs * HW, Cc)
+        ops.fsm_rows(hA, srcf, pairs=pairs, HW=HW, C_=Cc, a_rows=(2 * HW, 0), o_rows=(HW, 0))
+        ops.fsm_rows(hA, red, pairs=pairs, HW=HW, C_=Cc, a_rows=(2 * HW, HW), o_rows=(HW, 0), csr=fwd)
+        fused = ctx.new(pairs * HW, 2 * Cc)
+        ops.gemm(srcf, pk.wfuse, fused, M=pairs * HW, N=2 * Cc, K=18 * Cc, a1=red, csplit=Cc, bias=pk.bfuse,
+                 mode=ops.A_CONV3X3, Cin=2 * Cc, conv=(ctx.H, ctx.W, ctx.H, ctx.W, 1, 0))
+        out = ctx.new(T, Cc)
+        xb = ctx.xb_all[ctx.b0:, pk.xoff:pk.xoff + Cc]
+        ops.fsm_rows(fused[:, :Cc], out, pairs=pairs, HW=HW, C_=Cc, a_rows=(HW, 0), o_rows=(2 * HW, 0), res=hA,
+                     r_rows=(2 * HW, 0), bias=xb, bias_map=(2, 0, ctx.F))
+        ops.fsm_rows(fused[:, Cc:], out, pairs=pairs, HW=HW, C_=Cc, a_rows=(HW, 0), o_rows=(2 * HW, HW), res=hA,
+                     r_rows=(2 * HW, HW), bias=xb, bias_map=(2, 1, ctx.F), csr=bwd)
         return out
 
 

@@ -10,6 +10,7 @@ name-only stubs by tests/golden/make_goldens.py) on the blocks of oracle/blocks.
 from __future__ import annotations
 
 import copy
+import functools
 import math
 
 import torch
@@ -153,3 +154,17 @@ def fsm_block_forward(block: BasicTransformerBlock, hidden_states, encoder_hidde
         hidden_states = hidden_states + fused2
     hidden_states = block.attn2(block.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states) + hidden_states
     return block.ff(block.norm3(hidden_states)) + hidden_states
+
+
+def apply_fsm(model: nn.Module, track, track_res) -> None:
+    """patch_FSM.apply_patch + initialize_joint_layers + update_patch on an oracle UNet: every spatial
+    BasicTransformerBlock gets ``conv_fuse`` and the FSM forward (the temporal blocks stay stock, with_temporal_block
+    defaults to False, patch_FSM.py:645)."""
+    for m in model.modules():
+        if type(m) is BasicTransformerBlock:
+            initialize_fsm_layers(m)
+            m.forward = functools.partial(_fsm_forward, m, track, track_res)
+
+
+def _fsm_forward(block, track, track_res, hidden_states, encoder_hidden_states=None, **_):
+    return fsm_block_forward(block, hidden_states, encoder_hidden_states, track, track_res)

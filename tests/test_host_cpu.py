@@ -148,3 +148,40 @@ def test_product_does_not_import_the_oracle():
             "lkgd_amd.scheduler, lkgd_amd.lk_fuse, lkgd_amd.dist; "
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % REPO)
     subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_fsm_track_tables_match_reference_indexing():
+    """host side of the FSM hook (patch_FSM.py:381-403): CSR inversion of the tracks == what scatter_add would visit"""
+    from types import SimpleNamespace
+    from lkgd_amd import patch_FSM
+    from lkgd_amd._lib import LkgdHipError
+    g = torch.Generator().manual_seed(3)
+    pairs, P, fh, fw = 3, 50, 5, 7
+    src = torch.stack([torch.randint(0, 2 * fw, (pairs, P), generator=g),
+                       torch.randint(0, 2 * fh, (pairs, P), generator=g)], -1).float()
+    dst = torch.stack([torch.randint(-4, 2 * fw + 4, (pairs, P), generator=g),
+                       torch.randint(-4, 2 * fh + 4, (pairs, P), generator=g)], -1).float()
+    vis = (torch.rand(pairs, P, generator=g) > 0.3).float()
+    blk = SimpleNamespace(_tome_info={"fsm_tables": {}}, track=(src, dst, vis), track_res=(2 * fh, 2 * fw))
+    ctx = SimpleNamespace(H=fh, W=fw, HW=fh * fw, N=2 * pairs, device=torch.device("cpu"))
+    (off, pt, gi, v), (boff, bpt, bgi, _) = patch_FSM.track_tables(blk, ctx)
+    assert off.dtype == torch.int32 and off.numel() == pairs * fh * fw + 1 and int(off[-1]) == pairs * P
+    sidx = (src / 2).long()
+    sidx = sidx[..., 0] + sidx[..., 1] * fw
+    didx = (dst / 2).long()
+    didx = didx[..., 0].clamp(0, fw - 1) + didx[..., 1].clamp(0, fh - 1) * fw
+    for table, tgt, gat, o_, p_ in ((0, sidx, didx, off, pt), (1, didx, sidx, boff, bpt)):
+        g_ = gi if table == 0 else bgi
+        for pair in range(pairs):
+            for cell in range(fh * fw):
+                want = [pair * P + k for k in range(P) if int(tgt[pair, k]) == cell]     # increasing point order
+                r = pair * fh * fw + cell
+                assert p_[int(o_[r]):int(o_[r + 1])].tolist() == want
+        assert g_.tolist() == gat.reshape(-1).tolist()
+    assert torch.equal(v, vis.reshape(-1))
+    assert patch_FSM.track_tables(blk, ctx) is blk._tome_info["fsm_tables"][(fh, fw, 2 * pairs)]   # cached
+    bad = SimpleNamespace(_tome_info={"fsm_tables": {}}, track=(src - 100.0, dst, vis), track_res=(2 * fh, 2 * fw))
+    with pytest.raises(LkgdHipError):
+        patch_FSM.track_tables(bad, ctx)
+    with pytest.raises(LkgdHipError):
+        patch_FSM.track_tables(SimpleNamespace(_tome_info={}, track=None, track_res=None), ctx)

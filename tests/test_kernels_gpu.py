@@ -364,3 +364,65 @@ def test_errors_are_loud(ops):
         ops.gemm(a, w, out, M=128, N=128, K=100)
     with pytest.raises(LkgdHipError):
         ops.gemm(a.cpu(), w, out, M=128, N=128, K=64)
+
+
+# ------------------------------------------------------------------------------------------------ FSM row kernel (a15)
+@pytest.mark.parametrize("C_", [64, 320, 1280])
+def test_fsm_rows_copy_and_scatter_mean(C_):
+    """lkgd_fsm_rows: copy / combine mode is bit-exact; scatter-mean == sequential fp32 scatter_add / (count + 1e-6)"""
+    from lkgd_amd import ops
+    from lkgd_amd.patch_FSM import _csr
+    g = torch.Generator().manual_seed(C_)
+    pairs, HW, P = 3, 40, 90
+    hA = torch.randn(2 * pairs * HW, C_, generator=g).half()
+    res = torch.randn(2 * pairs * HW, C_, generator=g).half()
+    bias = torch.randn(2, C_ + 8, generator=g).half()[:, :C_]          # strided bias rows; entry -> row entry // 3
+    d = lambda t: t.to(DEV)
+    # de-interleave copy of the odd entries
+    out = torch.zeros(pairs * HW, C_, dtype=torch.float16, device=DEV)
+    ops.fsm_rows(d(hA), out, pairs=pairs, HW=HW, C_=C_, a_rows=(2 * HW, HW), o_rows=(HW, 0))
+    assert torch.equal(out.cpu(), hA.reshape(pairs, 2, HW, C_)[:, 1].reshape(-1, C_))
+    # combine: out[even] = a + res[even] + bias
+    a = torch.randn(pairs * HW, 2 * C_, generator=g).half()
+    out2 = torch.zeros(2 * pairs * HW, C_, dtype=torch.float16, device=DEV)
+    bdev = d(torch.randn(2, C_ + 8, generator=g).half())[:, :C_]
+    ops.fsm_rows(d(a)[:, C_:], out2, pairs=pairs, HW=HW, C_=C_, a_rows=(HW, 0), o_rows=(2 * HW, 0), res=d(res),
+                 r_rows=(2 * HW, 0), bias=bdev, bias_map=(2, 0, 3))
+    want = (a[:, C_:].float().reshape(pairs, HW, C_) + res.float().reshape(pairs, 2, HW, C_)[:, 0]
+            + bdev.cpu().float()[(2 * torch.arange(pairs)) // 3][:, None]).half()
+    got = out2.cpu().reshape(pairs, 2, HW, C_)
+    assert torch.equal(got[:, 0], want)
+    assert torch.equal(got[:, 1], torch.zeros_like(got[:, 1]))          # odd entries untouched
+    # scatter-mean with collisions, empty cells and invisible points
+    tgt = torch.randint(0, HW // 2, (pairs, P), generator=g)             # upper half of the cells stays empty
+    src = torch.randint(0, HW, (pairs, P), generator=g)
+    vis = (torch.rand(pairs, P, generator=g) > 0.3).float()
+    off, pt = _csr(d(tgt), pairs, HW)
+    out3 = torch.full((pairs * HW, C_), 7.0, dtype=torch.float16, device=DEV)
+    ops.fsm_rows(d(hA), out3, pairs=pairs, HW=HW, C_=C_, a_rows=(2 * HW, HW), o_rows=(HW, 0),
+                 csr=(off, pt, d(src.reshape(-1).int()), d(vis.reshape(-1))))
+    feats = hA.float().reshape(pairs, 2, HW, C_)[:, 1]
+    canvas = torch.zeros(pairs, HW, C_)
+    cnt = torch.zeros(pairs, HW, 1)
+    for p_ in range(pairs):
+        for k in range(P):                                               # sequential order of torch.scatter_add on CPU
+            if vis[p_, k] != 0:
+                canvas[p_, tgt[p_, k]] += feats[p_, src[p_, k]]
+            cnt[p_, tgt[p_, k]] += vis[p_, k]
+    want3 = (canvas / (cnt + 1e-6)).half().reshape(-1, C_)
+    assert torch.equal(out3.cpu(), want3)
+    assert float(out3.cpu().reshape(pairs, HW, C_)[:, HW // 2:].abs().max()) == 0.0
+
+
+def test_fsm_rows_rejects_bad_descriptors():
+    from lkgd_amd import ops
+    from lkgd_amd._lib import LkgdHipError
+    a = torch.zeros(16, 64, dtype=torch.float16, device=DEV)
+    with pytest.raises(LkgdHipError):
+        ops.fsm_rows(a[:, :60], a, pairs=1, HW=8, C_=60, a_rows=(8, 0), o_rows=(8, 0))       # C % 8
+    with pytest.raises(LkgdHipError):
+        ops.fsm_rows(a, a, pairs=0, HW=8, C_=64, a_rows=(8, 0), o_rows=(8, 0))
+    off = torch.zeros(9, dtype=torch.int32, device=DEV)
+    with pytest.raises(LkgdHipError):
+        ops.fsm_rows(a, a, pairs=1, HW=8, C_=64, a_rows=(8, 0), o_rows=(8, 0),
+                     csr=(off, off[:4], off[:3], torch.zeros(4, device=DEV)))

@@ -201,3 +201,133 @@ def test_patch_joint_attention_vs_reference_golden(golden_dir):
     assert _rel(run_temporal(), g["temporal_nojoint"]) < 5e-3
     patch.remove_patch(h)
     assert not h.spatial.enable_joint_attention
+
+
+# ------------------------------------------------------------------------------------------------ FSM hook (a15)
+def _fsm_holder(golden_seed):
+    from lkgd_amd import unet as pu
+    from oracle import blocks as ob
+    from oracle import unet as ou
+
+    class OHolder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.spatial = ob.BasicTransformerBlock(128, 2, 64, 1024)
+            self.temporal = ob.TemporalBasicTransformerBlock(128, 128, 2, 64, 1024)
+    torch.manual_seed(golden_seed)
+    oh = ou.init_weights_(OHolder(), golden_seed)
+
+    class Holder(pu._UNetBase):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.spatial = pu.BasicTransformerBlock(128, 2, 64, 1024)
+            self.temporal = pu.TemporalBasicTransformerBlock(128, 128, 2, 64, 1024)
+            self._pk, self._temb_reg, self._cross_reg = None, [], []
+
+        @property
+        def device(self):
+            return self.spatial.norm1.weight.device
+
+        def prepare(self):
+            if self._pk is not None:
+                return
+            self._cross_reg = []
+            self.spatial.pack(self)
+            self.temporal.pack(self)
+            folded = [a.fold_cross() for a in self._cross_reg]
+            self._pk = type("P", (), {})()
+            self._pk.w_x = torch.cat([w for w, _ in folded]).half().contiguous()
+            self._pk.b_x = torch.cat([b for _, b in folded]).contiguous()
+    h = Holder()
+    h.load_state_dict(oh.state_dict())
+    return oh, h.half().to(DEV)
+
+
+def test_patch_fsm_hook_vs_reference_golden(golden_dir):
+    """patch_FSM API on the HIP path: track gather / scatter-mean / conv_fuse / scatter back (patch_FSM.py:380-441)
+    against the output of the reference's own ToMeBlock"""
+    from lkgd_amd import ops, patch_FSM
+    from lkgd_amd import unet as pu
+    g = load_file(os.path.join(golden_dir, "patch_fsm.safetensors"))
+    _, h = _fsm_holder(51)
+    x, enc = g["in_x"], g["in_enc"]
+    nb, S, C = x.shape
+    fh, fw = 6, 8
+    track = (g["src_tracks"].to(DEV), g["dst_tracks"].to(DEV), g["vis"].to(DEV))
+    res = tuple(int(v) for v in g["track_res"])
+
+    def run():
+        h.prepare()
+        ctx = pu.Ctx(nb, 1, fh, fw, h.device)          # one cross-attention context row per batch entry
+        e = enc.reshape(nb, -1).half().to(DEV)
+        ctx.xb_all = torch.empty(nb, h._pk.w_x.shape[0], dtype=torch.float16, device=DEV)
+        ops.gemm(e, h._pk.w_x, ctx.xb_all, M=nb, N=h._pk.w_x.shape[0], K=1024, bias=h._pk.b_x)
+        return h.spatial.run(ctx, x.reshape(-1, C).half().to(DEV)).reshape(nb, S, C)
+
+    assert _rel(run(), g["fsm_off"]) < 5e-3                       # unpatched
+    patch_FSM.apply_patch(h)
+    patch_FSM.initialize_joint_layers(h)
+    patch_FSM.update_patch(h, track=track, track_res=res)
+    assert not hasattr(h.temporal, "conv_fuse") and h.spatial.conv_fuse.weight.shape == (2 * C, 2 * C, 3, 3)
+    assert _rel(run(), g["fsm_zero_init"]) < 5e-3                 # zero-init conv_fuse => identity
+    with torch.no_grad():
+        h.spatial.conv_fuse.weight.copy_(g["conv_fuse_w"])
+        h.spatial.conv_fuse.bias.copy_(g["conv_fuse_b"])
+    h.invalidate()
+    got = run()
+    assert _rel(got, g["fsm_on"]) < 5e-3
+    assert _rel(got, g["fsm_off"]) > 0.05                         # the hook really changes the output
+    assert torch.equal(got, run())                                 # deterministic (no atomics)
+    patch_FSM.set_joint_attention(h, False)
+    assert _rel(run(), g["fsm_off"]) < 5e-3
+    patch_FSM.set_joint_attention(h, True)
+    # new tracks invalidate the cached tables
+    patch_FSM.update_patch(h, track=(track[0], track[1], torch.zeros_like(track[2])), track_res=res)
+    allinv = run()
+    assert _rel(allinv, got) > 1e-3
+    patch_FSM.remove_patch(h)
+    assert _rel(run(), g["fsm_off"]) < 5e-3
+    from lkgd_amd._lib import LkgdHipError
+    with pytest.raises(LkgdHipError):
+        patch_FSM.apply_patch(h, with_temporal_block=True)
+
+
+def test_patch_fsm_full_unet_vs_oracle():
+    """FSM hook through the whole tiny UNet (all four resolution levels, per-level downsample of the tracks)"""
+    from lkgd_amd import patch_FSM
+    from oracle import patch_hooks as oph
+    o, m = _unet(seed=61)
+    B, F, H, W = 2, 4, 8, 8
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(B, F, 8, H, W, generator=g)
+    enc = torch.randn(B, 1, 1024, generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * B)
+    pairs, P = B * F // 2, 96
+    res = (2 * H, 2 * W)
+    src = torch.stack([torch.randint(0, 2 * W, (pairs, P), generator=g),
+                       torch.randint(0, 2 * H, (pairs, P), generator=g)], -1).float()
+    dst = (src + torch.randint(-5, 6, (pairs, P, 2), generator=g)).float()
+    vis = (torch.rand(pairs, P, generator=g) > 0.2).float()
+    patch_FSM.apply_patch(m)
+    patch_FSM.initialize_joint_layers(m)
+    patch_FSM.update_patch(m, track=(src, dst, vis), track_res=res)
+    oph.apply_fsm(o, (src, dst, vis), res)
+    gg = torch.Generator().manual_seed(63)
+    with torch.no_grad():
+        for (_, ob_), (_, pb) in zip([(n, b) for n, b in o.named_modules() if hasattr(b, "conv_fuse")],
+                                     [(n, b) for n, b in m.named_modules() if hasattr(b, "conv_fuse")]):
+            cw = torch.randn(ob_.conv_fuse.weight.shape, generator=gg) / (ob_.conv_fuse.weight[0].numel()) ** 0.5
+            cb = 0.1 * torch.randn(ob_.conv_fuse.bias.shape, generator=gg)
+            cw, cb = cw.half().float(), cb.half().float()
+            ob_.conv_fuse.weight.copy_(cw); ob_.conv_fuse.bias.copy_(cb)
+            pb.conv_fuse.weight.copy_(cw); pb.conv_fuse.bias.copy_(cb)
+    m.invalidate()
+    with torch.no_grad():
+        ref = o(x.half().float(), torch.tensor(1.3), enc.half().float(), added_time_ids=ids, return_dict=False)[0]
+        got = m(x.half().to(DEV), torch.tensor(1.3), enc.half().to(DEV), added_time_ids=ids.to(DEV),
+                return_dict=False)[0]
+        assert _rel(got, ref) < 1e-2
+        patch_FSM.set_joint_attention(m, False)
+        off = m(x.half().to(DEV), torch.tensor(1.3), enc.half().to(DEV), added_time_ids=ids.to(DEV),
+                return_dict=False)[0]
+    assert _rel(off, ref) > 2e-2
