@@ -90,12 +90,17 @@ def initialize_joint_layers(model, post="conv", add_norm=False):
         m.attn1n = copy.deepcopy(m.attn1)
         dim = m.attn1n.out_dim
         dev, dt = m.attn1.to_q.weight.device, m.attn1.to_q.weight.dtype
+        for stale in ("conv1n", "scale1n"):
+            if hasattr(m, stale):
+                delattr(m, stale)
         if post == "conv":
             m.conv1n = nn.Linear(dim, dim, bias=False, device=dev, dtype=dt)
             nn.init.zeros_(m.conv1n.weight)
-        elif post in ("scale", "conv_fuse"):
-            raise LkgdHipError(f"post='{post}' is not implemented on the HIP path (the SVD loaders use 'conv', "
-                               "utils/util.py:562)")
+        elif post == "scale":
+            m.scale1n = nn.Parameter(torch.zeros(1, 1, dim, device=dev, dtype=dt))
+        elif post == "conv_fuse":
+            m.conv1n = nn.Linear(2 * dim, 2 * dim, bias=False, device=dev, dtype=dt)
+            nn.init.zeros_(m.conv1n.weight)
         else:
             raise AssertionError(f"Unkown post processing type {post}")
         m.add_norm = False

@@ -94,6 +94,7 @@ class Ctx:
             raise LkgdHipError("frame sharding supports one batch entry per rank")
         self.temb_all: Optional[torch.Tensor] = None      # [B, sum C] fp16
         self.xb_all: Optional[torch.Tensor] = None        # [B, sum C] fp16
+        self.joint_blocks = None
         self.spatial_partner: Optional[torch.Tensor] = None   # joint attention maps (patch API)
         self.temporal_partner: Optional[torch.Tensor] = None
 
@@ -188,6 +189,37 @@ class Attention(nn.Module):
         return wo @ wv, _f32(self.to_out[0].bias)
 
 
+def _pack_joint_post(block, pk, spatial: bool):
+    """fold the joint branch's post-processing (patch/patch.py:484-494) into attn1n's out-projection:
+    conv:      conv1n(to_out(a))  = a @ (Wc Wo)^T + Wc bo
+    scale:     scale1n * to_out(a) = a @ (diag(s) Wo)^T + s * bo
+    conv_fuse: cat(o[mask], o[~mask]) @ Wc^T, chunked back = own/partner halves of Wc times Wo (K = 2C, spatial only;
+               the temporal branch applies no post for 'conv_fuse', patch.py:647-650)"""
+    post = getattr(block, "post", "conv")
+    wo = block.attn1n.to_out[0].weight.detach().to(torch.float32)
+    bo = block.attn1n.to_out[0].bias.detach().to(torch.float32)
+    C_ = wo.shape[0]
+    if post == "conv":
+        wc = block.conv1n.weight.detach().to(torch.float32)
+        pk.jw, pk.jb = pack_linear(wc @ wo), (wc @ bo).contiguous()
+    elif post == "scale":
+        sc = block.scale1n.detach().to(torch.float32).reshape(-1)
+        pk.jw, pk.jb = pack_linear(sc[:, None] * wo), (sc * bo).contiguous()
+    elif post == "conv_fuse" and spatial:
+        wc = block.conv1n.weight.detach().to(torch.float32)
+        own_m, par_m = wc[:C_, :C_], wc[:C_, C_:]          # masked entries: fx = o_m A^T + o_u B^T
+        own_u, par_u = wc[C_:, C_:], wc[C_:, :C_]          # unmasked:       fy = o_u D^T + o_m C^T
+        pk.jw_m = pack_linear(torch.cat([own_m @ wo, par_m @ wo], dim=1))
+        pk.jb_m = ((own_m + par_m) @ bo).contiguous()
+        pk.jw_u = pack_linear(torch.cat([own_u @ wo, par_u @ wo], dim=1))
+        pk.jb_u = ((own_u + par_u) @ bo).contiguous()
+    elif post == "conv_fuse":
+        pk.jw, pk.jb = pack_linear(wo), bo.contiguous()
+    else:
+        raise LkgdHipError(f"joint attention: unknown post '{post}'")
+    pk.post = post
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in: int, dim_out: int):
         super().__init__()
@@ -255,7 +287,7 @@ class BasicTransformerBlock(nn.Module):
         pk.xoff = model._register_cross(self.attn2)
         if hasattr(self, "attn1n"):
             pk.a1n = self.attn1n.pack_self(self.norm1)
-            pk.conv1n = pack_linear(self.conv1n.weight) if hasattr(self, "conv1n") else None
+            _pack_joint_post(self, pk, spatial=True)
         if hasattr(self, "conv_fuse"):      # FSM hook (lkgd_amd/patch_FSM.py)
             pk.wfuse, pk.bfuse = pack_conv3x3(self.conv_fuse.weight), _f32(self.conv_fuse.bias)
         self._pk = pk
@@ -284,10 +316,10 @@ class BasicTransformerBlock(nn.Module):
         return _ff(ctx, pk.ff, ln3, res1=h1)
 
     def _joint(self, ctx: Ctx, ln: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
-        """joint attention attn1n with the partner batch entry's K/V (patch/patch.py:438-501, post == "conv")"""
+        """joint attention attn1n with the partner batch entry's K/V (patch/patch.py:438-501); the post step
+        (conv1n / scale1n / conv_fuse) is folded into the out-projection, so the branch ends in ONE GEMM epilogue
+        h1 + joint_scale * post(attn1n(...))"""
         pk, T, Cc = self._pk, ln.shape[0], ln.shape[1]
-        if getattr(self, "post", "conv") != "conv" or pk.conv1n is None:
-            raise LkgdHipError("joint attention: only post='conv' is implemented on the HIP path")
         if ctx.spatial_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set (patch.set_joint_attention_mask)")
         qkv = ctx.new(T, 3 * Cc)
@@ -295,12 +327,21 @@ class BasicTransformerBlock(nn.Module):
         att = ctx.new(T, Cc)
         ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, self.attn1n.heads,
                          kv_batch_map=ctx.spatial_partner)
-        o1n = ctx.new(T, Cc)
-        ops.gemm(att, pk.a1n.wo, o1n, M=T, N=Cc, K=Cc, bias=pk.a1n.bo)
         out = ctx.new(T, Cc)
-        ops.gemm(o1n, pk.conv1n, out, M=T, N=Cc, K=Cc, s_acc=float(self.joint_scale), res1=h1)
+        js = float(self.joint_scale)
+        if pk.post != "conv_fuse":
+            ops.gemm(att, pk.jw, out, M=T, N=Cc, K=Cc, bias=pk.jb, s_acc=js, res1=h1)
+            return out
+        # conv_fuse: the i-th masked and i-th unmasked entry blocks are fused pairwise (:488-493) - one two-source GEMM
+        # per entry block, own rows | partner rows along K
+        if ctx.joint_blocks is None:
+            raise LkgdHipError("post='conv_fuse' needs as many masked as unmasked entries in joint_attn_mask")
+        for e0, n, p0, masked in ctx.joint_blocks:
+            r0, r1, q0 = e0 * ctx.HW, (e0 + n) * ctx.HW, p0 * ctx.HW
+            ops.gemm(att[r0:r1], pk.jw_m if masked else pk.jw_u, out[r0:r1], M=r1 - r0, N=Cc, K=2 * Cc,
+                     a1=att[q0:q0 + (r1 - r0)], csplit=Cc, bias=pk.jb_m if masked else pk.jb_u, s_acc=js,
+                     res1=h1[r0:r1])
         return out
-
 
     def _fsm(self, ctx: Ctx, hA: torch.Tensor) -> torch.Tensor:
         """track-guided fuse between even (src) and odd (dst) batch entries (patch/patch_FSM.py:380-441): gather dst
@@ -359,7 +400,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         pk.xoff = model._register_cross(self.attn2)
         if hasattr(self, "attn1n"):
             pk.a1n = self.attn1n.pack_self(self.norm1)
-            pk.conv1n = pack_linear(self.conv1n.weight) if hasattr(self, "conv1n") else None
+            _pack_joint_post(self, pk, spatial=False)
         self._pk = pk
 
     def run(self, ctx: Ctx, h_s: torch.Tensor, posemb: torch.Tensor, alpha: float, order: str) -> torch.Tensor:
@@ -404,8 +445,6 @@ class TemporalBasicTransformerBlock(nn.Module):
     def _joint(self, ctx: Ctx, ln1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
         """temporal joint branch (patch/patch.py:616-658): attn1n over the partner batch entry's frames"""
         pk, T, Cc = self._pk, ln1.shape[0], ln1.shape[1]
-        if getattr(self, "post", "conv") != "conv" or pk.conv1n is None:
-            raise LkgdHipError("temporal joint attention: only post='conv' is implemented on the HIP path")
         if ctx.temporal_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
         qkv = ctx.new(T, 3 * Cc)
@@ -413,10 +452,8 @@ class TemporalBasicTransformerBlock(nn.Module):
         att = ctx.new(T, Cc)
         ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
                           self.attn1n.heads, kv_b_map=ctx.temporal_partner)
-        o1n = ctx.new(T, Cc)
-        ops.gemm(att, pk.a1n.wo, o1n, M=T, N=Cc, K=Cc, bias=pk.a1n.bo)
         out = ctx.new(T, Cc)
-        ops.gemm(o1n, pk.conv1n, out, M=T, N=Cc, K=Cc, res1=m2)     # the temporal branch ignores joint_scale
+        ops.gemm(att, pk.jw, out, M=T, N=Cc, K=Cc, bias=pk.jb, res1=m2)   # post folded in; joint_scale is not applied here
         return out
 
 
@@ -963,6 +1000,15 @@ class _UNetBase(nn.Module):
             raise LkgdHipError("joint_attn_mask length must divide the UNet batch")
         ctx.spatial_partner = partner(ctx.N, ctx.F if flip else None)
         ctx.temporal_partner = partner(ctx.B, None)
+        # entry blocks for post == "conv_fuse": i-th masked block <-> i-th unmasked block (no flip, patch.py:488-493)
+        ml = [bool(v) for v in torch.as_tensor(mask).tolist()]
+        per = ctx.N // len(ml)
+        on, off = [j for j, v in enumerate(ml) if v], [j for j, v in enumerate(ml) if not v]
+        ctx.joint_blocks = None
+        if len(on) == len(off):
+            pj = {a: b for a, b in zip(on, off)}
+            pj.update({b: a for a, b in zip(on, off)})
+            ctx.joint_blocks = [(j * per, per, pj[j] * per, ml[j]) for j in range(len(ml))]
 
     def _run(self, sample, timestep, encoder_hidden_states, down_block_additional_residuals,
              mid_block_additional_residual, added_time_ids):

@@ -365,6 +365,28 @@ def gen_patch(patch_mod):
                 for n, p in holder.temporal.attn1n.named_parameters():
                     out["attn1n_temporal." + n] = p.clone()
             patch_mod.remove_patch(holder)
+        # the other post-processing variants of initialize_joint_layers (patch.py:146-158, :484-494)
+        for post in ("scale", "conv_fuse"):
+            patch_mod.apply_patch(holder, flip=False, with_spatial_block=True, with_temporal_block=True)
+            patch_mod.initialize_joint_layers(holder, post=post)
+            patch_mod.set_joint_attention_mask(holder, mask)
+            gg = torch.Generator().manual_seed(31 if post == "scale" else 32)
+            for name, blk in (("spatial", holder.spatial), ("temporal", holder.temporal)):
+                if post == "scale":
+                    blk.scale1n.copy_(torch.randn(1, 1, C, generator=gg))
+                    out[f"{post}.scale1n_{name}"] = blk.scale1n.detach().clone()
+                else:
+                    blk.conv1n.weight.copy_(torch.randn(2 * C, 2 * C, generator=gg) / (2 * C) ** 0.5)
+                    out[f"{post}.conv1n_{name}"] = blk.conv1n.weight.clone()
+                for n, p in blk.attn1n.named_parameters():
+                    p.add_(0.05 * torch.randn(p.shape, generator=gg))
+                    out[f"{post}.attn1n_{name}." + n] = p.detach().clone()
+            holder._tome_info["size"] = (4, frames, C, 4, 4)
+            patch_mod.set_joint_attention(holder, True)
+            patch_mod.set_joint_scale(holder, 0.75)
+            out[f"{post}.spatial_joint"] = holder.spatial(x, encoder_hidden_states=enc)
+            out[f"{post}.temporal_joint"] = holder.temporal(x, num_frames=frames, encoder_hidden_states=tctx)
+            patch_mod.remove_patch(holder)
     out["in_x"], out["in_enc"], out["in_tctx"] = x, enc, tctx
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "patch_joint.safetensors"))
     print("patch: joint vs nojoint delta %.4f" % (out["spatial_joint_noflip"] - out["spatial_nojoint"]).abs().max())

@@ -153,6 +153,30 @@ def test_patch_joint_hooks(golden_dir):
         torch.testing.assert_close(h.temporal(x, 3, tctx), g["temporal_nojoint"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("post", ["scale", "conv_fuse"])
+def test_patch_joint_post_variants(golden_dir, post):
+    """post = 'scale' / 'conv_fuse' of initialize_joint_layers (patch.py:146-158, applied at :484-494, :649-652)"""
+    g = load_file(os.path.join(golden_dir, "patch_joint.safetensors"))
+    torch.manual_seed(21)
+    h = ou.init_weights_(_Holder(), 21)
+    mask = torch.tensor([False, True, False, True])
+    x, enc, tctx = g["in_x"], g["in_enc"], g["in_tctx"]
+    with torch.no_grad():
+        for name, blk in (("spatial", h.spatial), ("temporal", h.temporal)):
+            oph.initialize_joint_layers(blk, post)
+            if post == "scale":
+                blk.scale1n.copy_(g[f"{post}.scale1n_{name}"])
+            else:
+                blk.conv1n.weight.copy_(g[f"{post}.conv1n_{name}"])
+            pre = f"{post}.attn1n_{name}."
+            blk.attn1n.load_state_dict({k[len(pre):]: v for k, v in g.items() if k.startswith(pre)})
+        h.spatial.joint_scale = 0.75
+        y = oph.basic_block_forward(h.spatial, x, enc, mask, enable_joint=True)
+        torch.testing.assert_close(y, g[f"{post}.spatial_joint"], rtol=1e-5, atol=1e-5)
+        y = oph.temporal_block_forward(h.temporal, x, 3, tctx, mask, enable_joint=True)
+        torch.testing.assert_close(y, g[f"{post}.temporal_joint"], rtol=1e-5, atol=1e-5)
+
+
 def test_patch_fsm_hook(golden_dir):
     """a15: track-guided fuse of patch/patch_FSM.py:380-441 against the reference's own ToMeBlock output"""
     g = load_file(os.path.join(golden_dir, "patch_fsm.safetensors"))

@@ -331,3 +331,50 @@ def test_patch_fsm_full_unet_vs_oracle():
         off = m(x.half().to(DEV), torch.tensor(1.3), enc.half().to(DEV), added_time_ids=ids.to(DEV),
                 return_dict=False)[0]
     assert _rel(off, ref) > 2e-2
+
+
+@pytest.mark.parametrize("post", ["scale", "conv_fuse"])
+def test_patch_joint_post_variants_vs_reference_golden(golden_dir, post):
+    """post = 'scale' / 'conv_fuse' (patch.py:146-158,:484-494) - folded into attn1n's out-projection on the HIP path"""
+    from lkgd_amd import ops, patch
+    from lkgd_amd import unet as pu
+    g = load_file(os.path.join(golden_dir, "patch_joint.safetensors"))
+    _, h = _fsm_holder(21)
+    frames, S, C = 3, 16, 128
+    x, enc, tctx = g["in_x"], g["in_enc"], g["in_tctx"]
+    patch.apply_patch(h, flip=False, with_spatial_block=True, with_temporal_block=True)
+    patch.initialize_joint_layers(h, post=post)
+    patch.set_joint_attention_mask(h, [False, True, False, True])
+    with torch.no_grad():
+        for name, blk in (("spatial", h.spatial), ("temporal", h.temporal)):
+            if post == "scale":
+                assert blk.scale1n.shape == (1, 1, C) and not hasattr(blk, "conv1n")
+                blk.scale1n.copy_(g[f"{post}.scale1n_{name}"])
+            else:
+                assert blk.conv1n.weight.shape == (2 * C, 2 * C)
+                blk.conv1n.weight.copy_(g[f"{post}.conv1n_{name}"])
+            pre = f"{post}.attn1n_{name}."
+            blk.attn1n.load_state_dict({k[len(pre):]: v for k, v in g.items() if k.startswith(pre)})
+    h.invalidate()
+    patch.set_joint_scale(h, 0.75)
+    h.prepare()
+    # spatial: one cross-attention context row per frame-image (as in the conv test above)
+    ctx = pu.Ctx(4, frames, 4, 4, h.device)
+    e = enc.reshape(4 * frames, -1).half().to(DEV)
+    ctx.xb_all = torch.empty(4 * frames, h._pk.w_x.shape[0], dtype=torch.float16, device=DEV)
+    ops.gemm(e, h._pk.w_x, ctx.xb_all, M=4 * frames, N=h._pk.w_x.shape[0], K=1024, bias=h._pk.b_x)
+    real = pu.Ctx(4, frames, 4, 4, h.device)
+    pu._UNetBase._joint_maps(h, real)
+    ctx.F = 1; ctx.B = 4 * frames
+    ctx.spatial_partner, ctx.joint_blocks = real.spatial_partner, real.joint_blocks
+    got = h.spatial.run(ctx, x.reshape(-1, C).half().to(DEV)).reshape(4 * frames, S, C)
+    assert _rel(got, g[f"{post}.spatial_joint"]) < 5e-3
+    # temporal
+    ctx = pu.Ctx(4, frames, 4, 4, h.device)
+    e = tctx.reshape(4 * S, -1).half().to(DEV)
+    ctx.xb_all = torch.empty(4 * S, h._pk.w_x.shape[0], dtype=torch.float16, device=DEV)
+    ops.gemm(e, h._pk.w_x, ctx.xb_all, M=4 * S, N=h._pk.w_x.shape[0], K=1024, bias=h._pk.b_x)
+    pu._UNetBase._joint_maps(h, ctx)
+    posemb = torch.zeros(frames, C, dtype=torch.float16, device=DEV)
+    got = h.temporal.run(ctx, x.reshape(-1, C).half().to(DEV), posemb, 0.0, (frames * S, S, S, 4 * S))
+    assert _rel(got.reshape(4 * frames, S, C), g[f"{post}.temporal_joint"]) < 5e-3
