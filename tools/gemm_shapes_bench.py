@@ -46,7 +46,7 @@ def shapes():
     return out
 
 
-def run(kind, d, iters=5):
+def run(kind, d, iters=5, variants=None):
     z = lambda *s: torch.randn(*s, device=DEV, dtype=torch.float16) * 0.1   # noqa: E731
     if kind == "conv":
         H, W, cin, cout = d["H"], d["W"], d["cin"], d["cout"]
@@ -76,19 +76,67 @@ def run(kind, d, iters=5):
         from lkgd_amd.packing import geglu_half
         fn = lambda: ops.gemm(a, w, out, M=M, N=N, K=K, bias=bias, geglu=geglu_half(N) if geglu else 0, res1=res)   # noqa
         flop = 2.0 * M * N * K
-    fn()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
+    def once():
         fn()
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / iters
-    return flop, ms
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / iters
+    if variants is None:
+        return flop, once()
+    # A/B inside one process, interleaved, best of 3 rounds: the clocks ramp over the first seconds of a process and
+    # comparisons across processes are confounded by that
+    from lkgd_amd import _lib
+    best = {}
+    for _ in range(3):
+        for v in variants:
+            _lib.lib().lkgd_debug_set_gemm_variant(v)
+            try:
+                t = once()
+            except Exception:          # variant not applicable to this shape
+                t = float("inf")
+            best[v] = min(best.get(v, float("inf")), t)
+    _lib.lib().lkgd_debug_set_gemm_variant(0)
+    return flop, best
+
+
+def warm(seconds=3.0):
+    a = torch.randn(8192, 8192, device=DEV, dtype=torch.float16)
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(20):
+            a @ a
+        torch.cuda.synchronize()
+
+
+def main_ab():
+    warm()
+    variants = [0, 1, 2, 3, 4, 5]
+    names = {0: "auto", 1: "t128", 2: "t256", 3: "strm", 4: "wide", 5: "rowp"}
+    print(f"{'shape':34s} {'cnt':>4s} " + " ".join(f"{names[v]:>8s}" for v in variants) + "   (ms per launch; * = best)")
+    tot = {v: 0.0 for v in variants}
+    tot_best = tot_f = 0.0
+    for name, cnt, kind, d in shapes():
+        flop, best = run(kind, d, variants=variants)
+        b = min(best.values())
+        tot_best += b * cnt
+        tot_f += flop * cnt
+        for v in variants:
+            tot[v] += best[v] * cnt
+        print(f"{name:34s} {cnt:4d} " + " ".join(f"{best[v]:7.3f}{'*' if best[v] == b else ' '}" for v in variants)
+              + f"   auto {flop / best[0] / 1e9:6.0f} TF/s, best {flop / b / 1e9:6.0f}", flush=True)
+    print(f"{'TOTAL ms (x count)':34s}      " + " ".join(f"{tot[v]:8.2f}" for v in variants)
+          + f"   best-of {tot_best:.2f} ms = {tot_f / tot_best / 1e9:.0f} TF/s; auto {tot_f / tot[0] / 1e9:.0f} TF/s")
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ab":
+        return main_ab()
+    warm()
     if len(sys.argv) > 1:
         from lkgd_amd import _lib
         _lib.lib().lkgd_debug_set_gemm_variant(int(sys.argv[1]))
