@@ -192,7 +192,7 @@ def main():
                 traffic = json.load(f)["gemm_family_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_{stream,wide}_kernel (MFMA GEMM / implicit-conv family)",
+        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_{stream,wide,pp,rowpanel}_kernel (MFMA GEMM / implicit-conv family)",
                     "achieved": round(achieved, 2),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "launches": len(events),

@@ -283,10 +283,12 @@ static int check_desc(const lkgd_gemm_desc* d) {
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_wide.hip
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
+extern "C" int lkgd_gemm_pp_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);       // gemm_pp.hip
 
 // tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128 ring,
 // 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320),
-// 5 = force the register-resident row-panel kernel where it applies (plain A, K <= 320)
+// 5 = force the register-resident row-panel kernel where it applies (plain A, K <= 320),
+// 6 = force the 256x256 ping-pong kernel where it applies
 static int gemm_variant_override = 0;
 extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = v; }
 
@@ -314,30 +316,55 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   const bool rows16 = d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->out) &&
                       (!d->res1 || (d->ldr1 % 8 == 0 && aligned16(d->res1))) &&
                       (!d->res2 || (d->ldr2 % 8 == 0 && aligned16(d->res2)));
-  // short-K projections: token panel in registers, weights streamed (gemm_rowpanel.hip)
-  const bool rp_ok = rows16 && d->mode == LKGD_A_PLAIN && d->K <= 320 && d->csplit >= d->K && d->geglu != 80;
-  if (rp_ok && (gemm_variant_override == 5 || (gemm_variant_override == 0 && d->M >= 4096 && d->K >= 192)))
-    return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
-  const bool wide_ok = d->geglu == 80 || d->geglu == 0;
-  // measured per shape (profiles/r01_gemm_shapes_*.txt): the 256x320 tile wins where K is deep enough to amortise its
-  // larger epilogue and single K-tile of prefetch (3x3 / temporal convs, FF-out at 1280 channels); short-K projections
-  // stay on the 256x128 streaming kernel (three-stage ring, cheaper epilogue)
-  const bool wide_auto = d->geglu == 80 || (d->geglu == 0 && d->N % 320 == 0 && d->M >= 8192 && d->K >= 960 &&
-                                            !(d->mode == LKGD_A_PLAIN && d->K < 5120 && d->N < 1280));
-  if (d->mode != LKGD_A_CONV3X3_C8 && wide_ok &&
-      (d->geglu == 80 || gemm_variant_override == 4 || (gemm_variant_override == 0 && wide_auto)))
-    return lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus);
-  if (rows16 && d->geglu != 80 &&
-      (gemm_variant_override == 3 || gemm_variant_override == 4 || (gemm_variant_override == 0 && d->M > 256)))
-    return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
-  if (d->geglu == 80) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the wide kernel
+  // ---- tile-program choice.  Rules are the per-shape winners of the interleaved A/B runs (tools/gemm_shapes_bench.py ab,
+  //      profiles/r01_gemm_shapes_ab*.txt), expressed through the quantities that explain them: how many workgroup
+  //      slots a tiling fills (a 256-row tiling of M = 16 128 x N = 640 is 126 tiles for 256 CUs), K depth (amortises
+  //      the epilogue and the pipeline fill), and N granularity (320-wide tiles for N = 320 / 640 / 1280).
+  const int v = gemm_variant_override;
+  const bool plain = d->mode == LKGD_A_PLAIN;
+  const bool rp_ok = rows16 && plain && d->K <= 320 && d->csplit >= d->K && d->geglu != 80;
+  const bool pp_ok = rows16 && d->geglu != 80 && d->mode != LKGD_A_CONV3X3_C8 && d->M < (1 << 24);
+  const bool wide_ok = (d->geglu == 80 || d->geglu == 0) && d->mode != LKGD_A_CONV3X3_C8;
+  const bool stream_ok = rows16 && d->geglu != 80;
+  const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
+  int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide, 5 = rowpanel, 6 = ping-pong
+  if (d->geglu == 80) {
+    pick = 4;                                            // 80-wide GEGLU interleave exists only in the 256x320 kernel
+  } else if (v != 0) {
+    pick = v;
+  } else if (rp_ok && d->M >= 4096 && d->K >= 192) {
+    pick = 5;                                            // K <= 320 projections at 258k rows: A read exactly once
+  } else if (d->M < 8192) {
+    // the 9x16 level (M = 4032): 256-row tilings leave most CUs idle; 128x128 at two workgroups per CU fills best.
+    // Wide-N projections there still prefer the 256x256 kernel (QKV: 16 x 15 tiles)
+    pick = (pp_ok && plain && d->N >= 2560 && d->M > 256 && !d->res1 && !d->geglu) ? 6 : 1;
+  } else if (pp_ok && plain && d->N >= 1920 && d->K >= 640) {
+    pick = 6;                                            // QKV and GEGLU projections at 640 / 1280 channels
+  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->K >= 960 && tiles_wide * 5 >= 4LL * cus) {
+    pick = 4;                                            // 3x3 / temporal convs, FF-out, N = 320 / 640 / 1280 with deep K
+  } else if (!plain && d->K >= 960 && tiles_wide * 5 < 4LL * cus) {
+    pick = 1;                                            // stride-2 convs: few rows, deep K
+  } else if (plain && d->K <= 640 && d->N <= 640) {
+    pick = 1;                                            // 640 x 640 projections: epilogue-bound, two workgroups per CU
+  } else {
+    pick = 3;
+  }
+  // applicability (forced variants fall back the same way)
+  if (pick == 5 && !rp_ok) pick = 1;
+  if (pick == 6 && !pp_ok) pick = 3;
+  if (pick == 4 && !wide_ok) pick = 3;
+  if (pick == 3 && (!stream_ok || d->M <= 256)) pick = (d->K >= 960 && d->M > 256) ? 2 : 1;
+  if (d->geglu == 80 && pick != 4) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the wide kernel
+  if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
+  if (pick == 6) return lkgd_gemm_pp_launch(d, (hipStream_t)stream, cus);
+  if (pick == 4) return lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus);
+  if (pick == 3) return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
   int tiles_n = (d->N + BN - 1) / BN;
   // deep-K problems (3x3 / temporal convs, K >= 960) take the 256x128 three-stage ring: its two K-tiles in flight hide
   // the HBM latency the two-stage kernel exposes every K-step.  Short-K GEMMs (K = 320/640 projections at 258k rows) are
   // epilogue-bound; they keep 128x128 tiles at two workgroups per CU so one workgroup's epilogue overlaps the other's
   // main loop (measured per shape: tools/gemm_shapes_bench.py, profiles/r01_gemm_shapes.txt).
-  const bool big = gemm_variant_override == 2 || (gemm_variant_override == 0 && d->K >= 960 && d->M > 256);
-  if (big) {
+  if (pick == 2) {
     int tiles_m = (d->M + BM2 - 1) / BM2;
     long long nwg = (long long)tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) return LKGD_E_SHAPE;

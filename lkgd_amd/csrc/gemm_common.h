@@ -10,15 +10,18 @@ struct ARow {
   int valid;
 };
 
+// MODE_ >= 0 fixes the A-operand mode at compile time (kernels instantiated per mode); -1 reads it from the descriptor
+template <int MODE_ = -1>
 __device__ __forceinline__ const half_t* a_source(const lkgd_gemm_desc& p, const ARow& r, int k0, int chunk) {
   const half_t* zero = (const half_t*)p.zeros;
+  const int mode = MODE_ >= 0 ? MODE_ : p.mode;
   if (!r.valid) return zero;
-  if (p.mode == LKGD_A_PLAIN) {
+  if (mode == LKGD_A_PLAIN) {
     int k = k0 + chunk * 8;
     if (k < p.csplit) return (const half_t*)p.a0 + r.base * p.lda0 + k;
     return (const half_t*)p.a1 + r.base * p.lda1 + (k - p.csplit);
   }
-  if (p.mode == LKGD_A_CONV3X3) {
+  if (mode == LKGD_A_CONV3X3) {
     int tap = k0 / p.Cin;
     int c = k0 - tap * p.Cin + chunk * 8;
     int ky = tap / 3, kx = tap - ky * 3;
@@ -29,7 +32,7 @@ __device__ __forceinline__ const half_t* a_source(const lkgd_gemm_desc& p, const
     if (c < p.csplit) return (const half_t*)p.a0 + row * p.lda0 + c;
     return (const half_t*)p.a1 + row * p.lda1 + (c - p.csplit);
   }
-  if (p.mode == LKGD_A_TCONV3) {
+  if (mode == LKGD_A_TCONV3) {
     int tap = k0 / p.Cin;
     int c = k0 - tap * p.Cin + chunk * 8;
     int f = r.y + tap - 1;
@@ -49,19 +52,21 @@ __device__ __forceinline__ const half_t* a_source(const lkgd_gemm_desc& p, const
 
 
 // per-thread decomposition of output row m into the gather state of its mode
+template <int MODE_ = -1>
 __device__ __forceinline__ ARow a_row(const lkgd_gemm_desc& p, int m) {
+  const int mode = MODE_ >= 0 ? MODE_ : p.mode;
   ARow r;
   r.valid = m < p.M;
   r.base = m; r.y = 0; r.x = 0;
   if (r.valid) {
-    if (p.mode == LKGD_A_CONV3X3 || p.mode == LKGD_A_CONV3X3_C8) {
+    if (mode == LKGD_A_CONV3X3 || mode == LKGD_A_CONV3X3_C8) {
       int hw = p.Hout * p.Wout;
       int n = m / hw, rem = m - n * hw;
       int y = rem / p.Wout, x = rem - y * p.Wout;
       r.base = (long long)n * p.Hin * p.Win;
       r.y = y * p.stride - 1;
       r.x = x * p.stride - 1;
-    } else if (p.mode == LKGD_A_TCONV3) {
+    } else if (mode == LKGD_A_TCONV3) {
       int bf = m / p.HW;                 // b*Floc + fl
       int b = bf / p.Floc;
       r.y = bf - b * p.Floc + p.f_off;   // global frame
@@ -83,11 +88,12 @@ struct AGather {
   int seg_k0, seg_end;
 };
 
-template <int NR>
+template <int NR, int MODE_ = -1>
 __device__ __forceinline__ void a_segment(const lkgd_gemm_desc& p, AGather<NR>& g, int k0, int schunk) {
   const half_t* zero = (const half_t*)p.zeros;
+  const int mode = MODE_ >= 0 ? MODE_ : p.mode;
   g.zmask = 0;
-  if (p.mode == LKGD_A_PLAIN) {
+  if (mode == LKGD_A_PLAIN) {
     const bool s1 = k0 >= p.csplit;
     g.seg_k0 = s1 ? p.csplit : 0;
     g.seg_end = s1 ? p.K : (p.csplit < p.K ? p.csplit : p.K);
@@ -98,7 +104,7 @@ __device__ __forceinline__ void a_segment(const lkgd_gemm_desc& p, AGather<NR>& 
       g.ptr[i] = r.valid ? q + schunk * 8 : zero;
       g.zmask |= (r.valid ? 0u : 1u) << i;
     }
-  } else if (p.mode == LKGD_A_CONV3X3) {
+  } else if (mode == LKGD_A_CONV3X3) {
     const int tap = k0 / p.Cin;
     const int c = k0 - tap * p.Cin;
     const bool s1 = c >= p.csplit;
@@ -116,7 +122,7 @@ __device__ __forceinline__ void a_segment(const lkgd_gemm_desc& p, AGather<NR>& 
       g.ptr[i] = ok ? q + schunk * 8 : zero;
       g.zmask |= (ok ? 0u : 1u) << i;
     }
-  } else if (p.mode == LKGD_A_TCONV3) {
+  } else if (mode == LKGD_A_TCONV3) {
     const int tap = k0 / p.Cin;
     g.seg_k0 = tap * p.Cin;
     g.seg_end = g.seg_k0 + p.Cin;
@@ -134,7 +140,7 @@ __device__ __forceinline__ void a_segment(const lkgd_gemm_desc& p, AGather<NR>& 
     g.seg_end = k0 + BK;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      g.ptr[i] = a_source(p, g.row[i], k0, schunk);
+      g.ptr[i] = a_source<MODE_>(p, g.row[i], k0, schunk);
       g.zmask |= 1u << i;     // pointer is final: no in-segment offset
     }
   }
