@@ -76,8 +76,9 @@ def build_unet(dev, tiny):
 
 
 def cpu_baseline(args):
-    """fp32 oracle on the host cores, bounded sample: ONE forward of the real-shaped UNet on the C1 geometry
-    (CFG batch 2 x 4 frames x 32x32 latent = 2.37 algorithmic TFLOP), extrapolated to the C2 metric by FLOPs."""
+    """fp32 oracle on the host cores, bounded sample: ONE forward of the real-shaped UNet on half the C1 geometry
+    (CFG batch 2 x 2 frames x 32x32 latent = 1.19 algorithmic TFLOP, 8-27 s on the boxes seen so far), extrapolated to
+    the C2 metric by FLOPs."""
     from oracle import unet as ou
     t0 = time.time()
     with torch.device("meta"):
@@ -93,7 +94,7 @@ def cpu_baseline(args):
             if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)):
                 m.weight.fill_(1.0)
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(2, 4, 8, 32, 32, generator=g)
+    x = torch.randn(2, 2, 8, 32, 32, generator=g)
     enc = torch.randn(2, 1, 1024, generator=g)
     ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
     t_build = time.time() - t0
@@ -101,7 +102,7 @@ def cpu_baseline(args):
     with torch.no_grad():
         o(x, torch.tensor(1.0), enc, added_time_ids=ids, return_dict=False)
     dt = time.time() - t0
-    tflop_sample = 2.37 if not args.tiny else 0.0
+    tflop_sample = 2.37 / 2 if not args.tiny else 0.0
     cores = torch.get_num_threads()
     if args.tiny:
         return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "tiny config (invalid)"}
@@ -109,8 +110,8 @@ def cpu_baseline(args):
     fps = args.frames / (args.inference_steps * UNET_TFLOP_C2 / tflops)
     return {"value": round(fps, 6), "unit": "frames/s (C2-equivalent, extrapolated by algorithmic FLOPs)",
             "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 (torch eager), one UNet forward of the real-shaped SVD UNet at CFG-batch 2 x 4 frames "
-                      f"x 32x32 latent (config 1 geometry, 2.37 TFLOP) in {dt:.1f} s = {tflops:.3f} TFLOP/s on {cores} "
+            "sample": f"oracle fp32 (torch eager), one UNet forward of the real-shaped SVD UNet at CFG-batch 2 x 2 frames "
+                      f"x 32x32 latent (half of config 1's geometry, {tflop_sample:.2f} TFLOP) in {dt:.1f} s = {tflops:.3f} TFLOP/s on {cores} "
                       f"threads (os.cpu_count={os.cpu_count()}); model build {t_build:.0f} s not counted"}
 
 

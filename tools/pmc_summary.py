@@ -21,7 +21,7 @@ def load(path, counter):
     return agg
 
 
-def main(fetch_csv, write_csv):
+def main(fetch_csv, write_csv, json_out=None):
     fe, wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     print(f"{'kernel':44s} {'launches':>8s} {'fetch MB/launch (x2 corrected)':>30s} {'write MB/launch':>16s} {'GB/s (profiled pass)':>22s}")
     rows = []
@@ -35,5 +35,20 @@ def main(fetch_csv, write_csv):
         print(f"{k[:44]:44s} {n:8d} {f:30.2f} {w:16.2f} {bw:22.1f}")
 
 
+    if json_out:
+        import json
+        fam = {k: v for k, v in fe.items() if "lkgd_gemm" in k}
+        launches = sum(v[0] for v in fam.values())
+        total = sum(v[1] * 1024 * 2 for v in fam.values()) + sum(wr.get(k, [0, 0.0, 0.0])[1] * 1024 for k in fam)
+        doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 0 "
+                         "--inference-steps 2`, gfx950 corrections per MI355X_MICROARCH.md (KiB units, FETCH_SIZE x2)",
+               "kernels": {k.split("(")[0]: {"launches": v[0], "fetch_mb": round(v[1] * 2048 / v[0] / 1e6, 2),
+                                             "write_mb": round(wr.get(k, [0, 0.0, 0.0])[1] * 1024 / v[0] / 1e6, 2)}
+                           for k, v in fam.items()},
+               "gemm_family_bytes_per_launch": int(total / max(launches, 1))}
+        with open(json_out, "w") as f:
+            json.dump(doc, f, indent=1)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
