@@ -155,17 +155,35 @@ __device__ __forceinline__ void pp_segment(const lkgd_gemm_desc& p, PPStage& st,
   }
 }
 
+// Linear tile index -> (tm, tn).  Tiles are ordered in column groups of PP_GW n-tiles, m-major inside a group, so the ~32
+// tiles an XCD works on at any time form an 8 x 4 block: a weight K-slice is shared by 8 CUs and an A K-slice by 4 (both
+// through that XCD's L2), and the group's weight strip (4 x 256 x K) stays L2-resident while the XCD walks down the rows.
+// With n fastest over ALL n-tiles (20 - 40 of them for the GEGLU / QKV projections) every m-row re-streamed the whole
+// weight matrix: 996 MB fetched per launch for 89 MB of operands (profiles/r01_pmc_hbm_traffic_pp.txt).
+#define PP_GW 4
+__device__ __forceinline__ void pp_tile(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int per_group = tiles_m * PP_GW;
+  const int g = tile / per_group;
+  const int r = tile - g * per_group;
+  const int n_first = g * PP_GW;
+  const int width = tiles_n - n_first < PP_GW ? tiles_n - n_first : PP_GW;
+  tm = r / width;
+  tn = n_first + (r - tm * width);
+}
+
 // move the staging state to the next K-tile of the stream (stays on the last one at the end of the stream: the extra
 // loads the uniform schedule issues there re-read valid memory into buffers nobody reads any more)
 template <int MODE>
-__device__ __forceinline__ void pp_advance(const lkgd_gemm_desc& p, PPStage& st, int total, int nk, int nc, int tiles_n,
+__device__ __forceinline__ void pp_advance(const lkgd_gemm_desc& p, PPStage& st, int total, int nk, int nc, int tiles_m,
+                                           int tiles_n,
                                            int srow, int schunk, float rcp0, float rcp1) {
   if (st.s + 1 >= total) return;
   ++st.s;
   if (++st.kt == nk) {
     st.kt = 0;
     st.tile += nc;
-    const int tm = st.tile / tiles_n, tn = st.tile - tm * tiles_n;
+    int tm, tn;
+    pp_tile(st.tile, tiles_m, tiles_n, tm, tn);
 #pragma unroll
     for (int i = 0; i < 4; ++i) st.rd[i] = pp_row<MODE>(p, tm * PBM + srow + 64 * i, rcp0, rcp1);
     // LDS row rr of B half hb holds channel  tn*256 + (rr>>5)*64 + hb*32 + (rr&31): a wave's 32 + 32 channels are then
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(PNT) void lkgd_gemm_pp_kernel(const lkgd_gemm_desc 
   st.tile = tile_begin - nc; st.kt = nk - 1; st.s = -1; st.seg_k0 = 0; st.seg_end = 0; st.zmask = 0; st.n0 = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { st.rd[i].base = -1; st.rd[i].yx = 0; st.aptr[i] = (const half_t*)p.zeros; }
-#define ADVANCE() pp_advance<MODE>(p, st, total, nk, nc, tiles_n, srow, schunk, rcp0, rcp1)
+#define ADVANCE() pp_advance<MODE>(p, st, total, nk, nc, tiles_m, tiles_n, srow, schunk, rcp0, rcp1)
 
   // LDS read bases inside a K-tile buffer.  Token rows of this wave in an A half: wr*64 + jj*32 + l31; channel rows in a
   // B half: wc*32 + l31.  Chunk swizzle (row>>1)&7 as written by the staging side:  chunk (2ks + h) ^ sw = (2ks) ^ (h ^ sw),
@@ -472,7 +490,8 @@ __global__ __launch_bounds__(PNT) void lkgd_gemm_pp_kernel(const lkgd_gemm_desc 
     if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the token groups: both run the epilogue together
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results must have left the matrix pipe
     // -------------------------------------------------------------------- epilogue of `tile`, straight from registers
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    pp_tile(tile, tiles_m, tiles_n, tm, tn);
     tile += nc;
     char* scr = smem + PSCR_OFF + w * 4096;              // 32 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
     const int n0 = tn * PBN + wc * 64;
