@@ -324,7 +324,7 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   const bool plain = d->mode == LKGD_A_PLAIN;
   const bool rp_ok = rows16 && plain && d->K <= 320 && d->csplit >= d->K && d->geglu != 80;
   const bool pp_ok = rows16 && d->geglu != 80 && d->mode != LKGD_A_CONV3X3_C8 && d->M < (1 << 24);
-  const bool wide_ok = (d->geglu == 80 || d->geglu == 0) && d->mode != LKGD_A_CONV3X3_C8;
+  const bool wide_ok = (d->geglu == 80 || d->geglu == 0) && d->mode != LKGD_A_CONV3X3_C8 && d->M < (1 << 24);
   const bool stream_ok = rows16 && d->geglu != 80;
   const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
   int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide, 5 = rowpanel, 6 = ping-pong
@@ -332,20 +332,14 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     pick = 4;                                            // 80-wide GEGLU interleave exists only in the 256x320 kernel
   } else if (v != 0) {
     pick = v;
-  } else if (rp_ok && d->M >= 4096 && d->K >= 192) {
-    pick = 5;                                            // K <= 320 projections at 258k rows: A read exactly once
+  } else if (rp_ok && d->M >= 4096 && d->K >= 192 && d->N != 320) {
+    pick = 5;                                            // K <= 320 QKV / GEGLU projections at 258k rows: A read exactly once
   } else if (d->M < 8192) {
-    // the 9x16 level (M = 4032): 256-row tilings leave most CUs idle; 128x128 at two workgroups per CU fills best.
-    // Wide-N projections there still prefer the 256x256 kernel (QKV: 16 x 15 tiles)
-    pick = (pp_ok && plain && d->N >= 2560 && d->M > 256 && !d->res1 && !d->geglu) ? 6 : 1;
-  } else if (pp_ok && plain && d->N >= 1920 && d->K >= 640) {
-    pick = 6;                                            // QKV and GEGLU projections at 640 / 1280 channels
-  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->K >= 960 && tiles_wide * 5 >= 4LL * cus) {
-    pick = 4;                                            // 3x3 / temporal convs, FF-out, N = 320 / 640 / 1280 with deep K
-  } else if (!plain && d->K >= 960 && tiles_wide * 5 < 4LL * cus) {
-    pick = 1;                                            // stride-2 convs: few rows, deep K
-  } else if (plain && d->K <= 640 && d->N <= 640) {
-    pick = 1;                                            // 640 x 640 projections: epilogue-bound, two workgroups per CU
+    // the 9x16 level (M = 4032): 256-row tilings leave most CUs idle; 128x128 at two workgroups per CU fills best,
+    // except for the wide-N projections (QKV: 16 x 12 tiles of 256x320)
+    pick = (wide_ok && plain && d->geglu == 0 && d->N % 320 == 0 && d->N >= 2560 && d->M > 256 && !d->res1) ? 4 : 1;
+  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->K >= 320 && tiles_wide * 2 >= cus) {
+    pick = 4;                                            // every N = 320 / 640 / 960 / 1280 / 1920 / 3840 shape of the model
   } else {
     pick = 3;
   }

@@ -153,6 +153,119 @@ __device__ __forceinline__ const half_t* a_chunk(const AGather<NR>& g, int i, in
   return g.ptr[i] + off;
 }
 
+// ---- lean gather -----------------------------------------------------------------------------------------------
+// For kernels whose accumulators leave few registers (gemm_pp.hip, gemm_wide.hip): per A row a compact descriptor
+// (2 registers) and the current segment's source pointer (2 registers).  The per-segment update has no divisions; the
+// per-tile decomposition of the row index uses a float-reciprocal division (exact for M < 2^24), so deriving a tile's
+// rows does not spike the register pressure inside a K-loop the way a_row()'s integer divisions do.
+struct RowD {
+  int base;     // conv: n*Hin*Win; tconv: b*F*HW + pixel; plain: m.   -1 = row past M (reads the zero page)
+  int yx;       // conv: (vy0 & 0xffff) | (vx0 << 16), top-left of the 3x3 window in the virtual source grid; tconv: frame
+};
+
+__device__ __forceinline__ int fast_div(int m, int d, float rcp_d) {   // floor(m / d) for 0 <= m < 2^24, d > 0
+  int q = (int)((float)m * rcp_d);
+  int r = m - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
+template <int MODE>
+__device__ __forceinline__ void lean_rcps(const lkgd_gemm_desc& p, float& rcp0, float& rcp1) {
+  rcp0 = 1.f; rcp1 = 1.f;
+  if (MODE == LKGD_A_CONV3X3) { rcp0 = 1.0f / (float)(p.Hout * p.Wout); rcp1 = 1.0f / (float)p.Wout; }
+  if (MODE == LKGD_A_TCONV3) { rcp0 = 1.0f / (float)p.HW; rcp1 = 1.0f / (float)p.Floc; }
+}
+
+template <int MODE>
+__device__ __forceinline__ RowD lean_row(const lkgd_gemm_desc& p, int m, float rcp0, float rcp1) {
+  RowD r;
+  r.base = -1; r.yx = 0;
+  if (m < p.M) {
+    if (MODE == LKGD_A_CONV3X3) {
+      const int hw = p.Hout * p.Wout;
+      const int n = fast_div(m, hw, rcp0), rem = m - n * hw;
+      const int y = fast_div(rem, p.Wout, rcp1), x = rem - y * p.Wout;
+      r.base = n * p.Hin * p.Win;
+      r.yx = ((y * p.stride - 1) & 0xffff) | ((x * p.stride - 1) << 16);
+    } else if (MODE == LKGD_A_TCONV3) {
+      const int bf = fast_div(m, p.HW, rcp0);               // b*Floc + fl
+      const int b = fast_div(bf, p.Floc, rcp1);
+      r.yx = bf - b * p.Floc + p.f_off;                      // global frame
+      r.base = b * p.F * p.HW + (m - bf * p.HW);             // + f*HW added per tap
+    } else {
+      r.base = m;
+    }
+  }
+  return r;
+}
+
+template <int NR>
+struct LeanGather {
+  RowD rd[NR];
+  const half_t* aptr[NR];       // source of this thread's A rows in the current segment (chunk offset included)
+  unsigned zmask;               // bit i: row i reads the zero page in this segment
+  int seg_k0, seg_end;          // K range of the current segment (wave-uniform)
+};
+
+// source pointers of the rows for the segment containing k0
+template <int MODE, int NR>
+__device__ __forceinline__ void lean_segment(const lkgd_gemm_desc& p, LeanGather<NR>& st, int k0, int schunk) {
+  const half_t* zero = (const half_t*)p.zeros;
+  st.zmask = 0;
+  if (MODE == LKGD_A_PLAIN) {
+    const bool s1 = k0 >= p.csplit;
+    st.seg_k0 = s1 ? p.csplit : 0;
+    st.seg_end = s1 ? p.K : (p.csplit < p.K ? p.csplit : p.K);
+    const half_t* src = (s1 ? (const half_t*)p.a1 : (const half_t*)p.a0) + schunk * 8;
+    const unsigned ld = s1 ? p.lda1 : p.lda0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const bool ok = st.rd[i].base >= 0;
+      st.aptr[i] = ok ? src + (unsigned long long)(unsigned)st.rd[i].base * ld : zero;
+      st.zmask |= (ok ? 0u : 1u) << i;
+    }
+  } else if (MODE == LKGD_A_CONV3X3) {
+    const int tap = k0 / p.Cin;                            // wave-uniform (scalar) division
+    const int cc = k0 - tap * p.Cin;
+    const bool s1 = cc >= p.csplit;
+    st.seg_k0 = tap * p.Cin + (s1 ? p.csplit : 0);
+    st.seg_end = tap * p.Cin + (s1 ? p.Cin : (p.csplit < p.Cin ? p.csplit : p.Cin));
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+    const half_t* src = (s1 ? (const half_t*)p.a1 : (const half_t*)p.a0) + schunk * 8;
+    const unsigned ld = s1 ? p.lda1 : p.lda0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int vy = (int)(short)(st.rd[i].yx & 0xffff) + ky, vx = (st.rd[i].yx >> 16) + kx;
+      const bool ok = st.rd[i].base >= 0 && (unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv;
+      const unsigned row = (unsigned)(st.rd[i].base + (vy >> p.ups) * p.Win + (vx >> p.ups));
+      st.aptr[i] = ok ? src + (unsigned long long)row * ld : zero;
+      st.zmask |= (ok ? 0u : 1u) << i;
+    }
+  } else {   // LKGD_A_TCONV3
+    const int tap = k0 / p.Cin;
+    st.seg_k0 = tap * p.Cin;
+    st.seg_end = st.seg_k0 + p.Cin;
+    const half_t* src = (const half_t*)p.a0 + schunk * 8;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int f = st.rd[i].yx + tap - 1;
+      const bool ok = st.rd[i].base >= 0 && (unsigned)f < (unsigned)p.F;
+      const unsigned row = (unsigned)(st.rd[i].base + f * p.HW);
+      st.aptr[i] = ok ? src + (unsigned long long)row * (unsigned)p.lda0 : zero;
+      st.zmask |= (ok ? 0u : 1u) << i;
+    }
+  }
+}
+
+// source of row i's chunk for K-tile k0 (k0 must lie in the current segment)
+template <int NR>
+__device__ __forceinline__ const half_t* lean_chunk(const LeanGather<NR>& st, int i, int k0) {
+  return st.aptr[i] + (((st.zmask >> i) & 1u) ? 0 : (k0 - st.seg_k0));
+}
+
 // XCD-aware, bijective block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), so each residue class
 // gets a contiguous range of tiles; inside the range n is fastest (the A tile is reused from that XCD's L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

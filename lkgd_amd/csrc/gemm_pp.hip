@@ -55,105 +55,11 @@ __device__ __forceinline__ float gelu_fast_pp(float x) {
   return 0.5f * x * (1.0f + erf_s);
 }
 
-// ---- lean gather state -------------------------------------------------------------------------------------------
-// Four A rows per thread.  Per row a compact descriptor (2 registers) and the current segment's source pointer
-// (2 registers); the per-segment update has no divisions, the per-tile decomposition of the row index uses a
-// float-reciprocal division (exact for M < 2^24).
-struct RowD {
-  int base;     // conv: n*Hin*Win; tconv: b*F*HW + pixel; plain: m.   -1 = row past M (reads the zero page)
-  int yx;       // conv: (vy0 & 0xffff) | (vx0 << 16), top-left of the 3x3 window in the virtual source grid; tconv: frame
-};
-
-__device__ __forceinline__ int fast_div(int m, int d, float rcp_d) {   // floor(m / d) for 0 <= m < 2^24, d > 0
-  int q = (int)((float)m * rcp_d);
-  int r = m - q * d;
-  q += (r >= d) ? 1 : 0;
-  q -= (r < 0) ? 1 : 0;
-  return q;
-}
-
-template <int MODE>
-__device__ __forceinline__ RowD pp_row(const lkgd_gemm_desc& p, int m, float rcp0, float rcp1) {
-  RowD r;
-  r.base = -1; r.yx = 0;
-  if (m < p.M) {
-    if (MODE == LKGD_A_CONV3X3) {
-      const int hw = p.Hout * p.Wout;
-      const int n = fast_div(m, hw, rcp0), rem = m - n * hw;
-      const int y = fast_div(rem, p.Wout, rcp1), x = rem - y * p.Wout;
-      r.base = n * p.Hin * p.Win;
-      r.yx = ((y * p.stride - 1) & 0xffff) | ((x * p.stride - 1) << 16);
-    } else if (MODE == LKGD_A_TCONV3) {
-      const int bf = fast_div(m, p.HW, rcp0);               // b*Floc + fl
-      const int b = fast_div(bf, p.Floc, rcp1);
-      r.yx = bf - b * p.Floc + p.f_off;                      // global frame
-      r.base = b * p.F * p.HW + (m - bf * p.HW);             // + f*HW added per tap
-    } else {
-      r.base = m;
-    }
-  }
-  return r;
-}
-
-struct PPStage {
-  RowD rd[4];
-  const half_t* aptr[4];        // source of this thread's four A rows in the current segment (chunk offset included)
-  unsigned zmask;               // bit i: row i reads the zero page in this segment
+// ---- staging state: the lean gather of gemm_common.h (four A rows per thread) + the weight row and stream position
+struct PPStage : LeanGather<4> {
   int n0;                       // channel of LDS row srow of B half 0
   int tile, kt, s;              // tile / K-tile / stream index of the K-tile the state describes       (wave-uniform)
-  int seg_k0, seg_end;          // K range of the current segment                                        (wave-uniform)
 };
-
-// source pointers of the 4 rows for the segment containing k0
-template <int MODE>
-__device__ __forceinline__ void pp_segment(const lkgd_gemm_desc& p, PPStage& st, int k0, int schunk) {
-  const half_t* zero = (const half_t*)p.zeros;
-  st.zmask = 0;
-  if (MODE == LKGD_A_PLAIN) {
-    const bool s1 = k0 >= p.csplit;
-    st.seg_k0 = s1 ? p.csplit : 0;
-    st.seg_end = s1 ? p.K : (p.csplit < p.K ? p.csplit : p.K);
-    const half_t* src = (s1 ? (const half_t*)p.a1 : (const half_t*)p.a0) + schunk * 8;
-    const unsigned ld = s1 ? p.lda1 : p.lda0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = st.rd[i].base >= 0;
-      st.aptr[i] = ok ? src + (unsigned long long)(unsigned)st.rd[i].base * ld : zero;
-      st.zmask |= (ok ? 0u : 1u) << i;
-    }
-  } else if (MODE == LKGD_A_CONV3X3) {
-    const int tap = k0 / p.Cin;                            // wave-uniform (scalar) division
-    const int cc = k0 - tap * p.Cin;
-    const bool s1 = cc >= p.csplit;
-    st.seg_k0 = tap * p.Cin + (s1 ? p.csplit : 0);
-    st.seg_end = tap * p.Cin + (s1 ? p.Cin : (p.csplit < p.Cin ? p.csplit : p.Cin));
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-    const half_t* src = (s1 ? (const half_t*)p.a1 : (const half_t*)p.a0) + schunk * 8;
-    const unsigned ld = s1 ? p.lda1 : p.lda0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int vy = (int)(short)(st.rd[i].yx & 0xffff) + ky, vx = (st.rd[i].yx >> 16) + kx;
-      const bool ok = st.rd[i].base >= 0 && (unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv;
-      const unsigned row = (unsigned)(st.rd[i].base + (vy >> p.ups) * p.Win + (vx >> p.ups));
-      st.aptr[i] = ok ? src + (unsigned long long)row * ld : zero;
-      st.zmask |= (ok ? 0u : 1u) << i;
-    }
-  } else {   // LKGD_A_TCONV3
-    const int tap = k0 / p.Cin;
-    st.seg_k0 = tap * p.Cin;
-    st.seg_end = st.seg_k0 + p.Cin;
-    const half_t* src = (const half_t*)p.a0 + schunk * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = st.rd[i].yx + tap - 1;
-      const bool ok = st.rd[i].base >= 0 && (unsigned)f < (unsigned)p.F;
-      const unsigned row = (unsigned)(st.rd[i].base + f * p.HW);
-      st.aptr[i] = ok ? src + (unsigned long long)row * (unsigned)p.lda0 : zero;
-      st.zmask |= (ok ? 0u : 1u) << i;
-    }
-  }
-}
 
 // Linear tile index -> (tm, tn).  Tiles are ordered in column groups of PP_GW n-tiles, m-major inside a group, so the ~32
 // tiles an XCD works on at any time form an 8 x 4 block: a weight K-slice is shared by 8 CUs and an A K-slice by 4 (both
@@ -185,13 +91,13 @@ __device__ __forceinline__ void pp_advance(const lkgd_gemm_desc& p, PPStage& st,
     int tm, tn;
     pp_tile(st.tile, tiles_m, tiles_n, tm, tn);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st.rd[i] = pp_row<MODE>(p, tm * PBM + srow + 64 * i, rcp0, rcp1);
+    for (int i = 0; i < 4; ++i) st.rd[i] = lean_row<MODE>(p, tm * PBM + srow + 64 * i, rcp0, rcp1);
     // LDS row rr of B half hb holds channel  tn*256 + (rr>>5)*64 + hb*32 + (rr&31): a wave's 32 + 32 channels are then
     // 64 CONSECUTIVE output channels.  This thread fills rows srow and srow+64 (= +128 channels) of both halves.
     st.n0 = tn * PBN + (srow >> 5) * 64 + (srow & 31);
     st.seg_end = 0;
   }
-  if (st.kt * BK >= st.seg_end) pp_segment<MODE>(p, st, st.kt * BK, schunk);
+  if (st.kt * BK >= st.seg_end) lean_segment<MODE, 4>(p, st, st.kt * BK, schunk);
 }
 
 __device__ __forceinline__ const half_t* pp_a(const PPStage& st, int i) {
@@ -418,9 +324,8 @@ __global__ __launch_bounds__(PNT) void lkgd_gemm_pp_kernel(const lkgd_gemm_desc 
 
   const int srow = t >> 3;
   const int schunk = (t & 7) ^ ((t >> 4) & 7);
-  float rcp0 = 1.f, rcp1 = 1.f;             // reciprocals of the row-index divisors (uniform)
-  if (MODE == LKGD_A_CONV3X3) { rcp0 = 1.0f / (float)(p.Hout * p.Wout); rcp1 = 1.0f / (float)p.Wout; }
-  if (MODE == LKGD_A_TCONV3) { rcp0 = 1.0f / (float)p.HW; rcp1 = 1.0f / (float)p.Floc; }
+  float rcp0, rcp1;                         // reciprocals of the row-index divisors (uniform)
+  lean_rcps<MODE>(p, rcp0, rcp1);
   PPStage st;
   st.tile = tile_begin - nc; st.kt = nk - 1; st.s = -1; st.seg_k0 = 0; st.seg_end = 0; st.zmask = 0; st.n0 = 0;
 #pragma unroll

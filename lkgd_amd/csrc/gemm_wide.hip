@@ -32,11 +32,60 @@ __device__ __forceinline__ float gelu_fast_w(float x) {
   return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
 }
 
-__global__ __launch_bounds__(WNT, 2) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n) {
+// ---- K-tile body (generated asm, tools/gen_wide_asm.py).  hipcc's allocator spills a few values of the C++ form of this
+// loop and reloads them next to the LDS-DMA issue; every scratch reload is followed by s_waitcnt vmcnt(0), which in the
+// 3x3-conv instantiation sat right behind the nine freshly issued DMA loads and serialised their latency with the MFMAs.
+// In the asm form the 160 accumulators are pinned in a[0:159], the fragments are 40 scratch VGPRs, and the only waits are
+// the counted lgkmcnt of the software-pipelined fragment reads.
+#define WIDE_WAIT_TOP "s_waitcnt lgkmcnt(0)\n\t"   /* no scalar load of the surrounding code in the counted LDS waits */
+#ifdef WIDE_X_NOSTAGE
+#define WIDE_LD(X) ""
+#else
+#define WIDE_LD(X) X
+#endif
+#include "gemm_wide_ktile.inc"
+
+struct WideIn {                 // what one K-tile body needs about the NEXT K-tile (its nine DMA loads), besides the
+  unsigned oB[5];               // A row sources in LeanGather::aptr: byte offsets of the five weight row chunks from wk
+  const half_t* wk;             // weights + K offset (wave-uniform)
+};
+
+template <bool FIRST>
+__device__ __forceinline__ void wide_ktile(int xa0, int xa1, int wa0, int wa1, const half_t* const (&pA)[4],
+                                           const WideIn& in, int m_a) {
+  half8_t x0, x1, x2, x3, x4, x5, x6, x7, w0, w1;
+#define WIDE_STMT(BODY)                                                                                                \
+  asm volatile(BODY                                                                                                    \
+               : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7), "=&v"(w0),    \
+                 "=&v"(w1)                                                                                             \
+               : "v"(xa0), "v"(xa1), "v"(wa0), "v"(wa1), "v"(pA[0]), "v"(pA[1]), "v"(pA[2]), "v"(pA[3]),               \
+                 "v"(in.oB[0]), "v"(in.oB[1]), "v"(in.oB[2]), "v"(in.oB[3]), "v"(in.oB[4]), "s"(in.wk), "s"(m_a)       \
+               : "memory", "scc", WIDE_AGPR_CLOBBERS)
+  if (FIRST) {
+    WIDE_STMT(WIDE_KTILE_ASM_FIRST);
+  } else {
+    WIDE_STMT(WIDE_KTILE_ASM_NEXT);
+  }
+#undef WIDE_STMT
+}
+
+// accumulator fragment (weight fragment i, token fragment j) out of the AGPRs; BASE = (4i + j) * 4
+template <int BASE>
+__device__ __forceinline__ float4_t wide_read_acc() {
+  float a, b, c, d;
+  asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%4+1]\n\t"
+               "v_accvgpr_read_b32 %2, a[%4+2]\n\tv_accvgpr_read_b32 %3, a[%4+3]"
+               : "=v"(a), "=v"(b), "=v"(c), "=v"(d)
+               : "i"(BASE));
+  return (float4_t){a, b, c, d};
+}
+
+template <int MODE>
+__global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
-  const int w = t >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = w >> 1, wc = w & 1;
   const int l15 = lane & 15, lq = lane >> 4;
 
@@ -54,93 +103,97 @@ __global__ __launch_bounds__(WNT, 2) void lkgd_gemm_wide_kernel(const lkgd_gemm_
   const int total = (my_tiles > 0 ? my_tiles : 0) * nk;
   if (total <= 0) return;
 
-  // ---- staging state
+  // ---- staging state: describes the K-tile whose loads are issued next
   const int srow = t >> 3;
   const int schunk = (t & 7) ^ ((t >> 4) & 7);
-  AGather<4> ag;                 // rows are re-derived per segment (register diet: 160 accumulators live)
-  int st_m0 = 0;
-  long long wbase = 0;        // element offset of this thread's first weight row chunk; rows srow + 64*i
-  int wvalid = 0;             // bit i: weight row srow + 64*i < N
-  int st_tile = tile_begin - nc, st_kt = nk;
-  auto stage = [&](int buf) {
-    if (st_kt == nk) {
-      st_kt = 0;
-      st_tile += nc;
-      const int tm = st_tile / tiles_n, tn = st_tile - tm * tiles_n;
-      st_m0 = tm * WBM + srow;
-      const int n = tn * WBN + srow;
-      wbase = (long long)n * p.K + schunk * 8;
-      wvalid = 0;
+  LeanGather<4> ag;           // 2-register row descriptors, division-free segment updates (gemm_common.h)
+  float rcp0, rcp1;
+  lean_rcps<MODE>(p, rcp0, rcp1);
+  int st_tile = tile_begin - nc, st_kt = nk - 1, st_s = -1;
+  ag.seg_k0 = 0; ag.seg_end = 0; ag.zmask = 0;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) wvalid |= (n + 64 * i < p.N ? 1 : 0) << i;
-      ag.seg_end = 0;
+  for (int i = 0; i < 4; ++i) { ag.rd[i].base = -1; ag.rd[i].yx = 0; ag.aptr[i] = (const half_t*)p.zeros; }
+  WideIn in;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) in.oB[i] = 0;
+  const half_t* wbase = (const half_t*)p.w;
+  asm volatile("" : "+s"(wbase));            // an opaque SGPR pair: kept (or spilled to a lane), never re-loaded from kernarg
+  // move to the next K-tile of the stream (stays on the last one at the end: the loads the uniform K-tile body issues there
+  // re-read valid memory into the stage nobody reads any more) and return its DMA sources
+  auto next_in = [&](WideIn& in) {
+    if (st_s + 1 < total) {
+      ++st_s;
+      if (++st_kt == nk) {
+        st_kt = 0;
+        st_tile += nc;
+        const int tm = st_tile / tiles_n, tn = st_tile - tm * tiles_n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ag.rd[i] = lean_row<MODE>(p, tm * WBM + srow + 64 * i, rcp0, rcp1);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          int n = tn * WBN + srow + 64 * i;
+          n = n < p.N ? n : p.N - 1;     // clamped: channels past N are computed on a copy of the last row, never stored
+          in.oB[i] = ((unsigned)n * (unsigned)p.K + schunk * 8) * 2u;
+        }
+        ag.seg_end = 0;
+      }
+      if (st_kt * BK >= ag.seg_end) {
+        lean_segment<MODE, 4>(p, ag, st_kt * BK, schunk);       // aptr = the rows' sources at the segment's first K-tile
+      } else {
+        // within a segment a row's source advances by one K-tile (128 bytes); zero-page rows stay
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ag.aptr[i] += ((ag.zmask >> i) & 1u) ? 0 : BK;
+      }
     }
-    const int k0 = st_kt * BK;
-    if (k0 >= ag.seg_end) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ag.row[i] = a_row(p, st_m0 + 64 * i);
-      a_segment<4>(p, ag, k0, schunk);
-    }
-    char* sx = smem + buf * WSTAGE_BYTES;
-    char* sw = sx + WBM * BK * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(a_chunk<4>(ag, i, k0), sx + (w * 64 + 512 * i) * 16);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const half_t* src = (wvalid >> i) & 1 ? (const half_t*)p.w + wbase + (long long)(64 * i) * p.K + k0
-                                            : (const half_t*)p.zeros;
-      glds16(src, sw + (w * 64 + 512 * i) * 16);
-    }
-    ++st_kt;
+    in.wk = wbase + st_kt * BK;
   };
-
-  // acc[ni][mi]: 16 channels x 16 tokens; lane = token (l15), registers = 4 consecutive channels at 4*lq
-  float4_t acc[10][4];
-#pragma unroll
-  for (int i = 0; i < 10; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   // fragment rows: tokens wr*64 + mi*16 + l15, weights wc*160 + ni*16 + l15.  The swizzle key (row>>1)&7 is the same
   // for every fragment of a lane (16*mi, 16*ni, 64*wr, 160*wc are all 0 mod 16), so every fragment address is
-  // base + compile-time offset: two chunk offsets (one per k-step) per lane, nothing else in registers
+  // base + compile-time offset: two chunk offsets (one per k-step) per lane
   const int skey = (l15 >> 1) & 7;
-  const int x_base = (wr * 64 + l15) * 128;
-  const int w_base = WBM * BK * 2 + (wc * 160 + l15) * 128;
-  const int ch0 = ((0 + lq) ^ skey) << 4, ch1 = ((4 + lq) ^ skey) << 4;
+  int xa0, xa1, wa0, wa1;       // LDS addresses of fragment 0 (tokens / weights, K-step 0 / 1) in the CURRENT stage
+  {
+    const int x_base = (wr * 64 + l15) * 128;
+    const int w_base = WBM * BK * 2 + (wc * 160 + l15) * 128;
+    const int ch0 = ((0 + lq) ^ skey) << 4, ch1 = ((4 + lq) ^ skey) << 4;
+    xa0 = x_base + ch0; xa1 = x_base + ch1; wa0 = w_base + ch0; wa1 = w_base + ch1;
+  }
 
-  stage(0);
+  // ---- K-tile 0 -> stage 0
+  {
+    next_in(in);
+    char* sx = smem + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(ag.aptr[i], sx + 8192 * i);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) glds16((const half_t*)((const char*)in.wk + in.oB[i]), sx + WBM * BK * 2 + 8192 * i);
+  }
+  next_in(in);                  // K-tile 1
+
   int cur = 0, kt = 0, tile = tile_begin;
   bool skip_wait = false;
+#pragma unroll 1
   for (int s = 0; s < total; ++s) {
-    // K-tile s must have landed (it is the only LDS-DMA batch in flight at this point)
+    // K-tile s must have landed (it is the only LDS-DMA batch in flight at this point); the K-tile body starts with the
+    // workgroup barrier, issues K-tile s+1's loads into the other stage and computes K-tile s
     if (!skip_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     skip_wait = false;
-    __builtin_amdgcn_s_barrier();
-    if (s + 1 < total) stage(cur ^ 1);
-    const char* sb = smem + cur * WSTAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const char* sk_ = sb + (ks ? ch1 : ch0);
-      half8_t xf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xf[j] = *(const half8_t*)(sk_ + x_base + j * 2048);
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        half8_t wf = *(const half8_t*)(sk_ + w_base + i * 2048);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[j], acc[i][j], 0, 0, 0);
-      }
+    const int m_a = (cur ^ 1) * WSTAGE_BYTES + w * 1024;
+    if (kt == 0) wide_ktile<true>(xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    else wide_ktile<false>(xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    next_in(in);                // K-tile s+2's sources, for the next body
+    {
+      const int d = cur ? -WSTAGE_BYTES : WSTAGE_BYTES;      // the other stage becomes the current one
+      xa0 += d; xa1 += d; wa0 += d; wa1 += d;
     }
     cur ^= 1;
 
     if (++kt == nk) {
       // ---------------------------------------------------------------- epilogue of `tile`, straight from registers.
-      // Take step s+1's ring wait first (only K-tile s+1 is outstanding), so epilogue traffic never sits before it.
-      if (s + 1 < total) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        skip_wait = true;
-      }
+      // Take step s+1's wait first (only K-tile s+1 is outstanding), so epilogue traffic never sits before it.
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // + the last MFMAs have left the pipe
+      skip_wait = true;
       kt = 0;
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
       tile += nc;
@@ -150,79 +203,82 @@ __global__ __launch_bounds__(WNT, 2) void lkgd_gemm_wide_kernel(const lkgd_gemm_
       const half_t* r1p = (const half_t*)p.res1;
       const half_t* r2p = (const half_t*)p.res2;
       half_t* outp = (half_t*)p.out;
-      if (!p.geglu) {
+      // one token fragment (16 tokens x 160 channels) at a time
+      auto epi = [&](int j, const float4_t (&e)[10]) {
+        const long long m = m0 + j * 16;
+        if (m >= p.M) return;
+        if (!p.geglu) {
+          long long idx = 0;
+          if (rbp) idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          __builtin_amdgcn_sched_barrier(0);     // keep one token fragment's loads/stores from piling onto the next
-          const long long m = m0 + j * 16;
-          if (m < p.M) {
-            long long idx = 0;
-            if (rbp) idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
+          for (int i = 0; i < 10; ++i) {
+            const int n = n0 + i * 16;
+            if (n < p.N) {
+              float4_t v = e[i];
+              if (p.bias) v += *(const float4_t*)(p.bias + n);
+              if (rbp) {
+                half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + n);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-              const int n = n0 + i * 16;
-              if (n < p.N) {
-                float4_t v = acc[i][j];
-                if (p.bias) v += *(const float4_t*)(p.bias + n);
-                if (rbp) {
-                  half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + n);
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
-                }
-                v *= p.s_acc;
-                if (r1p) {
-                  half4_t r = *(const half4_t*)(r1p + m * p.ldr1 + n);
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] += p.r1 * (float)r[e];
-                }
-                if (r2p) {
-                  half4_t r = *(const half4_t*)(r2p + m * p.ldr2 + n);
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] += p.r2 * (float)r[e];
-                }
-                half4_t o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-                *(half4_t*)(outp + m * p.ldc + n) = o;
+                for (int x = 0; x < 4; ++x) v[x] += (float)rb[x];
               }
-            }
-          }
-        }
-      } else {
-        // wave channels [0,80) = hidden, [80,160) = gate of output columns tn*160 + wc*80 + [0,80)
-        const int oc0 = tn * 160 + wc * 80 + 4 * lq;
+              v *= p.s_acc;
+              if (r1p) {
+                half4_t r = *(const half4_t*)(r1p + m * p.ldr1 + n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          __builtin_amdgcn_sched_barrier(0);
-          const long long m = m0 + j * 16;
-          if (m < p.M) {
+                for (int x = 0; x < 4; ++x) v[x] += p.r1 * (float)r[x];
+              }
+              if (r2p) {
+                half4_t r = *(const half4_t*)(r2p + m * p.ldr2 + n);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-              float4_t hv = acc[i][j], gv = acc[i + 5][j];
-              if (p.bias) {
-                hv += *(const float4_t*)(p.bias + n0 + i * 16);
-                gv += *(const float4_t*)(p.bias + n0 + 80 + i * 16);
+                for (int x = 0; x < 4; ++x) v[x] += p.r2 * (float)r[x];
               }
               half4_t o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (half_t)(hv[e] * gelu_fast_w(gv[e]));
-              *(half4_t*)(outp + m * p.ldc + oc0 + i * 16) = o;
+              for (int x = 0; x < 4; ++x) o[x] = (half_t)v[x];
+              *(half4_t*)(outp + m * p.ldc + n) = o;
             }
           }
+        } else {
+          // wave channels [0,80) = hidden, [80,160) = gate of output columns tn*160 + wc*80 + [0,80)
+          const int oc0 = tn * 160 + wc * 80 + 4 * lq;
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            float4_t hv = e[i], gv = e[i + 5];
+            if (p.bias) {
+              hv += *(const float4_t*)(p.bias + n0 + i * 16);
+              gv += *(const float4_t*)(p.bias + n0 + 80 + i * 16);
+            }
+            half4_t o;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] = (half_t)(hv[x] * gelu_fast_w(gv[x]));
+            *(half4_t*)(outp + m * p.ldc + oc0 + i * 16) = o;
+          }
         }
-      }
-#pragma unroll
-      for (int i = 0; i < 10; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      };
+#define WIDE_EPI(J)                                                                                                \
+  {                                                                                                                \
+    const float4_t e[10] = {wide_read_acc<(0 + J) * 4>(),  wide_read_acc<(4 + J) * 4>(),  wide_read_acc<(8 + J) * 4>(),  \
+                            wide_read_acc<(12 + J) * 4>(), wide_read_acc<(16 + J) * 4>(), wide_read_acc<(20 + J) * 4>(), \
+                            wide_read_acc<(24 + J) * 4>(), wide_read_acc<(28 + J) * 4>(), wide_read_acc<(32 + J) * 4>(), \
+                            wide_read_acc<(36 + J) * 4>()};                                                        \
+    epi(J, e);                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);  /* keep one token fragment's loads/stores from piling onto the next */   \
+  }
+      WIDE_EPI(0) WIDE_EPI(1) WIDE_EPI(2) WIDE_EPI(3)
+#undef WIDE_EPI
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's trailing loads must land before the LDS is released
 }
 
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)lkgd_gemm_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) !=
+    if (hipFuncSetAttribute((const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WLDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WLDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) !=
         hipSuccess)
       return LKGD_E_LAUNCH;
     attr_set = true;
@@ -231,6 +287,14 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
   long long ntiles = (long long)tiles_m * tiles_n;
   if (ntiles > 0x7fffffffLL) return LKGD_E_SHAPE;
   int grid = ntiles < cus ? (int)ntiles : cus;
-  hipLaunchKernelGGL(lkgd_gemm_wide_kernel, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+  if (d->M >= (1 << 24)) return LKGD_E_SHAPE;            // float-reciprocal row decomposition (gemm_common.h)
+  if (d->mode == LKGD_A_PLAIN)
+    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+  else if (d->mode == LKGD_A_CONV3X3)
+    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+  else if (d->mode == LKGD_A_TCONV3)
+    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+  else
+    return LKGD_E_MODE;
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }

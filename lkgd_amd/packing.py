@@ -42,16 +42,18 @@ def geglu_perm(inner: int, half: int = 32, device=None) -> torch.Tensor:
     return torch.cat([t, t + inner], dim=1).reshape(-1)
 
 
-def geglu_half(n_packed_rows: int) -> int:
-    """interleave width the kernels want for a GEGLU projection with 2*inner = n_packed_rows rows"""
-    # the wide (256x320) kernel supports an 80-wide interleave, but at the GEGLU shapes of this model (K = C <= 1280)
-    # the 256x128 streaming kernel measures faster, so 32 it is
+def geglu_half(n_packed_rows: int, k: int = 0) -> int:
+    """interleave width the kernels want for a GEGLU projection with 2*inner = n_packed_rows rows and K = k inputs"""
+    # K <= 320 (the 320-channel level): the register-resident row-panel kernel, 32 hidden | 32 gate per wave.
+    # Otherwise the 256x320 kernel, 80 | 80 per wave, when the rows tile by 320 (measured: profiles/r01_gemm_shapes_ab*.txt)
+    if k > 320 and n_packed_rows % 320 == 0:
+        return 80
     return 32
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor, half: int = None):
     inner = w.shape[0] // 2
     if half is None:
-        half = geglu_half(w.shape[0])
+        half = geglu_half(w.shape[0], w.shape[1])
     perm = geglu_perm(inner, half, w.device)
     return w[perm].to(torch.float16).contiguous(), b[perm].to(torch.float32).contiguous(), half

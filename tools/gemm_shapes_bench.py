@@ -74,7 +74,8 @@ def run(kind, d, iters=5, variants=None):
         bias = torch.zeros(N, device=DEV)
         res = None if (geglu or os.environ.get('NORES')) else torch.zeros(M, N, device=DEV, dtype=torch.float16)
         from lkgd_amd.packing import geglu_half
-        fn = lambda: ops.gemm(a, w, out, M=M, N=N, K=K, bias=bias, geglu=geglu_half(N) if geglu else 0, res1=res)   # noqa
+        gw = [geglu_half(N)]       # interleave width; the forced 256x320 variant runs its own 80-wide packing
+        fn = lambda: ops.gemm(a, w, out, M=M, N=N, K=K, bias=bias, geglu=gw[0] if geglu else 0, res1=res)   # noqa
         flop = 2.0 * M * N * K
     def once():
         fn()
@@ -95,6 +96,8 @@ def run(kind, d, iters=5, variants=None):
     for _ in range(3):
         for v in variants:
             _lib.lib().lkgd_debug_set_gemm_variant(v)
+            if kind == "geglu":
+                gw[0] = 80 if v == 4 else 32
             try:
                 t = once()
             except Exception:          # variant not applicable to this shape
