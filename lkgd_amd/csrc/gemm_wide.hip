@@ -50,23 +50,35 @@ struct WideIn {                 // what one K-tile body needs about the NEXT K-t
   const half_t* wk;             // weights + K offset (wave-uniform)
 };
 
+// statement A: barrier, K-step 0 (fragment reads, the nine DMA loads of the next K-tile, 40 MFMAs) and the reads of K-step 1's
+// first fragments, which leave in x1 / w0
 template <bool FIRST>
-__device__ __forceinline__ void wide_ktile(int xa0, int xa1, int wa0, int wa1, const half_t* const (&pA)[4],
-                                           const WideIn& in, int m_a) {
-  half8_t x0, x1, x2, x3, x4, x5, x6, x7, w0, w1;
+__device__ __forceinline__ void wide_ktile_a(half8_t (&x1)[4], half8_t& w0, int xa0, int xa1, int wa0, int wa1,
+                                             const half_t* const (&pA)[4], const WideIn& in, int m_a) {
+  half8_t x0, x1_, x2, x3, w1;
 #define WIDE_STMT(BODY)                                                                                                \
   asm volatile(BODY                                                                                                    \
-               : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7), "=&v"(w0),    \
-                 "=&v"(w1)                                                                                             \
+               : "=&v"(x0), "=&v"(x1_), "=&v"(x2), "=&v"(x3), "=&v"(x1[0]), "=&v"(x1[1]), "=&v"(x1[2]), "=&v"(x1[3]),  \
+                 "=&v"(w0), "=&v"(w1)                                                                                  \
                : "v"(xa0), "v"(xa1), "v"(wa0), "v"(wa1), "v"(pA[0]), "v"(pA[1]), "v"(pA[2]), "v"(pA[3]),               \
                  "v"(in.oB[0]), "v"(in.oB[1]), "v"(in.oB[2]), "v"(in.oB[3]), "v"(in.oB[4]), "s"(in.wk), "s"(m_a)       \
                : "memory", "scc", WIDE_AGPR_CLOBBERS)
   if (FIRST) {
-    WIDE_STMT(WIDE_KTILE_ASM_FIRST);
+    WIDE_STMT(WIDE_KTILE_ASM_FIRST_A);
   } else {
-    WIDE_STMT(WIDE_KTILE_ASM_NEXT);
+    WIDE_STMT(WIDE_KTILE_ASM_NEXT_A);
   }
 #undef WIDE_STMT
+}
+
+// statement B: K-step 1 (40 MFMAs).  The C++ between A and B prepares the NEXT K-tile's sources while K-step 0's MFMAs drain
+// (between two K-tiles it would sit behind the barrier with the matrix pipe idle).
+__device__ __forceinline__ void wide_ktile_b(const half8_t (&x1)[4], half8_t w0, int wa1) {
+  half8_t w1;
+  asm volatile(WIDE_KTILE_ASM_B
+               : "=&v"(w1), "+v"(w0)
+               : "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]), "v"(wa1)
+               : "memory", WIDE_AGPR_CLOBBERS);
 }
 
 // accumulator fragment (weight fragment i, token fragment j) out of the AGPRs; BASE = (4i + j) * 4
@@ -180,9 +192,12 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
     if (!skip_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     skip_wait = false;
     const int m_a = (cur ^ 1) * WSTAGE_BYTES + w * 1024;
-    if (kt == 0) wide_ktile<true>(xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
-    else wide_ktile<false>(xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    half8_t x1[4], w0;
+    if (kt == 0) wide_ktile_a<true>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    else wide_ktile_a<false>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    const int wa1_now = wa1;
     next_in(in);                // K-tile s+2's sources, for the next body
+    wide_ktile_b(x1, w0, wa1_now);
     {
       const int d = cur ? -WSTAGE_BYTES : WSTAGE_BYTES;      // the other stage becomes the current one
       xa0 += d; xa1 += d; wa0 += d; wa1 += d;

@@ -74,7 +74,7 @@ def run(kind, d, iters=5, variants=None):
         bias = torch.zeros(N, device=DEV)
         res = None if (geglu or os.environ.get('NORES')) else torch.zeros(M, N, device=DEV, dtype=torch.float16)
         from lkgd_amd.packing import geglu_half
-        gw = [geglu_half(N)]       # interleave width; the forced 256x320 variant runs its own 80-wide packing
+        gw = [geglu_half(N, K)]       # interleave width; the forced 256x320 variant runs its own 80-wide packing
         fn = lambda: ops.gemm(a, w, out, M=M, N=N, K=K, bias=bias, geglu=gw[0] if geglu else 0, res1=res)   # noqa
         flop = 2.0 * M * N * K
     def once():
@@ -97,7 +97,7 @@ def run(kind, d, iters=5, variants=None):
         for v in variants:
             _lib.lib().lkgd_debug_set_gemm_variant(v)
             if kind == "geglu":
-                gw[0] = 80 if v == 4 else 32
+                gw[0] = 80 if v == 4 else (geglu_half(N, K) if v == 0 else 32)
             try:
                 t = once()
             except Exception:          # variant not applicable to this shape
