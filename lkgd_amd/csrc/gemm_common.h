@@ -266,6 +266,23 @@ __device__ __forceinline__ const half_t* lean_chunk(const LeanGather<NR>& st, in
   return st.aptr[i] + (((st.zmask >> i) & 1u) ? 0 : (k0 - st.seg_k0));
 }
 
+// Linear tile index -> (tm, tn) for the persistent kernels.  Tiles are ordered in column groups of GW n-tiles, m-major
+// inside a group, so the ~32 tiles an XCD works on at any time form an (32/GW) x GW block: a weight K-slice is shared by
+// 32/GW CUs and an A K-slice by GW (both through that XCD's L2), and the group's weight strip stays L2-resident while
+// the XCD walks down the rows.  With n fastest over ALL n-tiles (20 - 40 of them for the GEGLU / QKV projections) every
+// m-row re-streamed the whole weight matrix: 996 MB fetched per launch for 89 MB of operands
+// (profiles/r01_pmc_hbm_traffic_pp.txt).
+template <int GW>
+__device__ __forceinline__ void supertile(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int per_group = tiles_m * GW;
+  const int g = tile / per_group;
+  const int r = tile - g * per_group;
+  const int n_first = g * GW;
+  const int width = tiles_n - n_first < GW ? tiles_n - n_first : GW;
+  tm = r / width;
+  tn = n_first + (r - tm * width);
+}
+
 // XCD-aware, bijective block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), so each residue class
 // gets a contiguous range of tiles; inside the range n is fastest (the A tile is reused from that XCD's L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

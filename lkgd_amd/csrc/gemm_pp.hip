@@ -61,21 +61,7 @@ struct PPStage : LeanGather<4> {
   int tile, kt, s;              // tile / K-tile / stream index of the K-tile the state describes       (wave-uniform)
 };
 
-// Linear tile index -> (tm, tn).  Tiles are ordered in column groups of PP_GW n-tiles, m-major inside a group, so the ~32
-// tiles an XCD works on at any time form an 8 x 4 block: a weight K-slice is shared by 8 CUs and an A K-slice by 4 (both
-// through that XCD's L2), and the group's weight strip (4 x 256 x K) stays L2-resident while the XCD walks down the rows.
-// With n fastest over ALL n-tiles (20 - 40 of them for the GEGLU / QKV projections) every m-row re-streamed the whole
-// weight matrix: 996 MB fetched per launch for 89 MB of operands (profiles/r01_pmc_hbm_traffic_pp.txt).
-#define PP_GW 4
-__device__ __forceinline__ void pp_tile(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int per_group = tiles_m * PP_GW;
-  const int g = tile / per_group;
-  const int r = tile - g * per_group;
-  const int n_first = g * PP_GW;
-  const int width = tiles_n - n_first < PP_GW ? tiles_n - n_first : PP_GW;
-  tm = r / width;
-  tn = n_first + (r - tm * width);
-}
+#define PP_GW 4     // supertile width (gemm_common.h)
 
 // move the staging state to the next K-tile of the stream (stays on the last one at the end of the stream: the extra
 // loads the uniform schedule issues there re-read valid memory into buffers nobody reads any more)
@@ -89,7 +75,7 @@ __device__ __forceinline__ void pp_advance(const lkgd_gemm_desc& p, PPStage& st,
     st.kt = 0;
     st.tile += nc;
     int tm, tn;
-    pp_tile(st.tile, tiles_m, tiles_n, tm, tn);
+    supertile<PP_GW>(st.tile, tiles_m, tiles_n, tm, tn);
 #pragma unroll
     for (int i = 0; i < 4; ++i) st.rd[i] = lean_row<MODE>(p, tm * PBM + srow + 64 * i, rcp0, rcp1);
     // LDS row rr of B half hb holds channel  tn*256 + (rr>>5)*64 + hb*32 + (rr&31): a wave's 32 + 32 channels are then
@@ -396,7 +382,7 @@ __global__ __launch_bounds__(PNT) void lkgd_gemm_pp_kernel(const lkgd_gemm_desc 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results must have left the matrix pipe
     // -------------------------------------------------------------------- epilogue of `tile`, straight from registers
     int tm, tn;
-    pp_tile(tile, tiles_m, tiles_n, tm, tn);
+    supertile<PP_GW>(tile, tiles_m, tiles_n, tm, tn);
     tile += nc;
     char* scr = smem + PSCR_OFF + w * 4096;              // 32 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
     const int n0 = tn * PBN + wc * 64;

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
       if (++st_kt == nk) {
         st_kt = 0;
         st_tile += nc;
-        const int tm = st_tile / tiles_n, tn = st_tile - tm * tiles_n;
+        int tm, tn;
+        supertile<4>(st_tile, tiles_m, tiles_n, tm, tn);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ag.rd[i] = lean_row<MODE>(p, tm * WBM + srow + 64 * i, rcp0, rcp1);
 #pragma unroll
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
       asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // + the last MFMAs have left the pipe
       skip_wait = true;
       kt = 0;
-      const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+      int tm, tn;
+      supertile<4>(tile, tiles_m, tiles_n, tm, tn);
       tile += nc;
       const int m0 = tm * WBM + wr * 64 + l15;
       const int n0 = tn * WBN + wc * 160 + 4 * lq;
