@@ -332,8 +332,10 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     pick = 4;                                            // 80-wide GEGLU interleave exists only in the 256x320 kernel
   } else if (v != 0) {
     pick = v;
-  } else if (rp_ok && d->M >= 4096 && d->K >= 192 && d->N != 320) {
-    pick = 5;                                            // K <= 320 QKV / GEGLU projections at 258k rows: A read exactly once
+  } else if (rp_ok && d->M >= 4096 && d->K >= 192 && (d->N != 320 || d->res1)) {
+    // K <= 320 projections at 258k rows: A read exactly once.  The 320 x 320 ones only when they carry a residual (its
+    // row-coalesced epilogue wins there; without one the 256x320 kernel is ahead)
+    pick = 5;
   } else if (d->M < 8192) {
     // the 9x16 level (M = 4032): 256-row tilings leave most CUs idle; 128x128 at two workgroups per CU fills best,
     // except for the wide-N projections (QKV: 16 x 12 tiles of 256x320)
