@@ -1,8 +1,12 @@
 // Spatial self-attention, head_dim 64, fp16 in / fp32 softmax+accumulate (include/lkgd_hip.h section 4).
 //
-// Flash-style for gfx950: one 256-thread workgroup = 4 waves x 32 query rows; K/V tiles of 64 keys are staged
-// through registers into a double-buffered LDS ring (loads for tile j+1 are issued before the MFMAs of tile j and
-// written after them: one barrier per tile).
+// Flash-style for gfx950: one 256-thread workgroup = 4 waves x 32 query rows; K/V tiles of 64 keys stream through an
+// LDS ring filled by LDS-DMA (global_load_lds_dwordx4, the XOR swizzles applied on the source side, no staging
+// registers: 120 VGPRs, four waves per SIMD): the next tile is issued right after the barrier that opens a tile; one
+// barrier per tile.  Measured on this kernel (tools/micro/attn_pmc.sh, attn_lib.py): VALU issue 62 % and MFMA 35 % of
+// SIMD time, a wave is stalled two thirds of its life; removing every exp changes the time by 6 %, a deeper K/V ring by
+// nothing, interleaving the MFMA accumulators by nothing: the per-wave chain QK^T -> max -> exp -> PV is latency-bound
+// and only more resident waves help.
 //   S^T = K . Q^T   "swapped" product: v_mfma_f32_32x32x16_f16 with A = K rows (ds_read_b128 from an XOR-swizzled
 //                   [key][64] image) and B = Q^T held in registers, so a lane owns ONE query column and 32 of the
 //                   tile's 64 scores: row max / row sum are 31 register ops + one cross-half shuffle.
@@ -14,7 +18,10 @@
 
 #define QBLK 128
 #define KVBLK 64
-#define ATT_LDS (2 * 2 * KVBLK * 64 * 2)  // 2 stages x (K 8 KiB + V 8 KiB)
+#ifndef ATT_NST
+#define ATT_NST 2   // 2 stages (32 KiB) keep four workgroups per CU; a third stage measured 4 % slower (occupancy 3)
+#endif
+#define ATT_LDS (ATT_NST * 2 * KVBLK * 64 * 2)  // 3 stages x (K 8 KiB + V 8 KiB)
 
 __device__ __forceinline__ int k_lds_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_lds_off(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4); }
@@ -48,29 +55,24 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(qp + ks * 16);
 
-  // ---- staging map: thread moves 16-byte chunks (row = id>>3, c = id&7), ids t and t+256, for K and for V
+  // ---- staging map: thread t fills 16-byte chunk c = t & 7 of LDS rows srow0 and srow0 + 32, for K and for V.  LDS-DMA
+  //      writes lane-linearly (wave base + lane*16 = 8 rows x 8 chunks per wave), so the chunk a position holds is
+  //      chosen on the SOURCE side: position c of row r holds source chunk c ^ swizzle(r)
   const half_t* kbase = k + (long long)kvn * S * ldk + head * 64;
   const half_t* vbase = v + (long long)kvn * S * ldv + head * 64;
   const int srow0 = t >> 3, sc = t & 7;
-  uint4 kr0, kr1, vr0, vr1;
-#define LOAD_TILE(tile)                                                        \
+  const int kc0 = (sc ^ ((srow0 >> 1) & 7)) * 8, kc1 = (sc ^ (((srow0 + 32) >> 1) & 7)) * 8;
+  const int vc0 = (sc ^ (((srow0 >> 1) & 1) << 2)) * 8, vc1 = (sc ^ ((((srow0 + 32) >> 1) & 1) << 2)) * 8;
+#define ISSUE_TILE(tile, st)                                                   \
   {                                                                            \
     int key0_ = (tile) * KVBLK + srow0, key1_ = key0_ + 32;                    \
     if (key0_ >= S) key0_ = S - 1; /* clamped rows are masked in the scores */ \
     if (key1_ >= S) key1_ = S - 1;                                             \
-    kr0 = *(const uint4*)(kbase + (long long)key0_ * ldk + sc * 8);            \
-    kr1 = *(const uint4*)(kbase + (long long)key1_ * ldk + sc * 8);            \
-    vr0 = *(const uint4*)(vbase + (long long)key0_ * ldv + sc * 8);            \
-    vr1 = *(const uint4*)(vbase + (long long)key1_ * ldv + sc * 8);            \
-  }
-#define STORE_TILE(buf)                                       \
-  {                                                           \
-    char* kb_ = smem + (buf) * (2 * KVBLK * 128);             \
-    char* vb_ = kb_ + KVBLK * 128;                            \
-    *(uint4*)(kb_ + k_lds_off(srow0, sc)) = kr0;              \
-    *(uint4*)(kb_ + k_lds_off(srow0 + 32, sc)) = kr1;         \
-    *(uint4*)(vb_ + v_lds_off(srow0, sc)) = vr0;              \
-    *(uint4*)(vb_ + v_lds_off(srow0 + 32, sc)) = vr1;         \
+    char* kb_ = smem + (st) * (2 * KVBLK * 128) + w * 1024;                    \
+    glds16(kbase + (long long)key0_ * ldk + kc0, kb_);                         \
+    glds16(kbase + (long long)key1_ * ldk + kc1, kb_ + 32 * 128);              \
+    glds16(vbase + (long long)key0_ * ldv + vc0, kb_ + KVBLK * 128);           \
+    glds16(vbase + (long long)key1_ * ldv + vc1, kb_ + KVBLK * 128 + 32 * 128); \
   }
 
   float16_t oacc[2];
@@ -81,9 +83,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
   float m_run = -1e30f, l_run = 0.f;
 
   const int ntiles = (S + KVBLK - 1) / KVBLK;
-  LOAD_TILE(0);
-  STORE_TILE(0);
-  __syncthreads();
+  ISSUE_TILE(0, 0);
+  if (ATT_NST > 2 && ntiles > 1) ISSUE_TILE(1, 1);
 
   // transposed-read lane constants: 16-lane group -> (h, dgrp); lane in group i -> (row q4 = i>>2, col part = i&3)
   const int i16 = lane & 15;
@@ -92,20 +93,32 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
   const int tr_c = dgrp * 2 + ((i16 & 3) >> 1);   // 16-byte chunk inside the 32-column d-fragment
   const int tr_sub = (i16 & 1) * 8;
 
+  int cur = 0;
   for (int j = 0; j < ntiles; ++j) {
-    const int cur = j & 1;
-    if (j + 1 < ntiles) LOAD_TILE(j + 1);
+    // tile j has landed (this thread's four loads; the barrier publishes everyone's) - tile j+1 may stay in flight - and
+    // every wave is done with tile j-1, whose stage takes tile j+2
+    if (ATT_NST > 2 && j + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + ATT_NST - 1 < ntiles) {
+      const int nst = cur == 0 ? ATT_NST - 1 : cur - 1;  // (j + ATT_NST - 1) % ATT_NST
+      ISSUE_TILE(j + ATT_NST - 1, nst);
+    }
     const char* kb = smem + cur * (2 * KVBLK * 128);
     const char* vb = kb + KVBLK * 128;
 
     // ---- S^T tile: 64 keys x 32 queries per wave
+    // (K-step outer, key fragment inner: consecutive MFMAs alternate between the two accumulators instead of forming
+    // two chains of four back-to-back dependent ones)
     float16_t s[2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[f][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
         half8_t kf = *(const half8_t*)(kb + k_lds_off(32 * f + l31, ks * 2 + h));
         s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
       }
@@ -161,11 +174,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
 
     // ---- O^T += V^T . P^T : k-slot (half h, element jj) of k-step (f, ss) is key 32f + 16ss + 8(jj>>2) + 4h + (jj&3)
 #pragma unroll
-    for (int df = 0; df < 2; ++df) {
+    for (int f = 0; f < 2; ++f) {
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
+        for (int df = 0; df < 2; ++df) {     // d-fragment innermost: the two output accumulators alternate
           int row0 = 32 * f + 16 * ss + tr_row;
           fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
               (__attribute__((address_space(3))) fp16x4_t*)(vb + v_lds_off(row0, df * 4 + tr_c) + tr_sub));
@@ -176,8 +189,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
           oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[f][ss], oacc[df], 0, 0, 0);
         }
     }
-    if (j + 1 < ntiles) STORE_TILE(cur ^ 1);
-    __syncthreads();
+    cur = cur == ATT_NST - 1 ? 0 : cur + 1;
   }
 
   // ---- normalise and store: lane owns query row qrow, d = 32*df + 8*(r>>2) + 4*h + (r&3)
