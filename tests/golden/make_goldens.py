@@ -13,6 +13,8 @@ therefore everything the reference itself implements on the path:
                              ``forward`` (LK signature incl. the latent-knowledge fuse), tiny config
 * patch_joint.safetensors <- patch/patch.py ``apply_patch`` + ``ToMeBlock.forward`` / ``forward_temporal`` joint branch
 * patch_fsm.safetensors   <- patch/patch_FSM.py ``apply_patch`` + ``ToMeBlock.forward`` FSM branch (:380-441)
+* controlnet.safetensors  <- models/controlnet_sdv.py ``ControlNetSDVModel.forward`` (conditioning embedding, encoder,
+                             zero convolutions, conditioning_scale) and its residuals fed to the stock UNet
 * loop.safetensors        <- pipeline/pipeline_stable_video_diffusion_trans.py ``__call__`` (output_type="latent")
                              with stand-in CLIP/VAE stages (boundary stages, outside the hot path)
 
@@ -132,7 +134,7 @@ def install_stubs():
     su.KarrasDiffusionSchedulers = enum.Enum("KarrasDiffusionSchedulers", "EulerDiscreteScheduler DDIMScheduler")
     su.SchedulerMixin = type("SchedulerMixin", (), {})
     ld = _mod("diffusers.loaders")
-    for n in ("UNet2DConditionLoadersMixin", "PeftAdapterMixin", "FromSingleFileMixin"):
+    for n in ("UNet2DConditionLoadersMixin", "PeftAdapterMixin", "FromSingleFileMixin", "FromOriginalModelMixin"):
         setattr(ld, n, type(n, (), {}))
     dm = _mod("diffusers.models")
     dm.AutoencoderKLTemporalDecoder = type("AutoencoderKLTemporalDecoder", (), {})
@@ -142,8 +144,12 @@ def install_stubs():
     ap.AttentionProcessor = type("AttentionProcessor", (), {})
     ap.AttnProcessor = type("AttnProcessor", (), {})
     ap.Attention = ob.Attention
+    ap.ADDED_KV_ATTENTION_PROCESSORS = ()
+    ap.AttnAddedKVProcessor = type("AttnAddedKVProcessor", (), {})
     em = _mod("diffusers.models.embeddings")
     em.TimestepEmbedding, em.Timesteps = ob.TimestepEmbedding, ob.Timesteps
+    for n in ("TextImageProjection", "TextImageTimeEmbedding", "TextTimeEmbedding"):
+        setattr(em, n, type(n, (nn.Module,), {}))
     mu = _mod("diffusers.models.modeling_utils")
     mu.ModelMixin = type("ModelMixin", (nn.Module,), {})
     _mod("diffusers.models.unets")
@@ -309,6 +315,40 @@ def gen_unet(ref_stock, ref_lk):
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_wiring.safetensors"))
     print("unet wiring: stock std %.4f ctrl std %.4f lk std %.4f" % (
         out["stock_out"].std(), out["stock_out_ctrl"].std(), out["lk_out"].std()))
+
+
+def gen_controlnet(ref_ctrl, ref_stock):
+    """ControlNet-SVD encoder: the reference class over the restated blocks, tiny config"""
+    from oracle import controlnet as oc
+    kw = {k: v for k, v in TINY.__dict__.items()}
+    inp = tiny_inputs()
+    g = torch.Generator().manual_seed(71)
+    cond = torch.rand(2, 4, 3, 64, 64, generator=g)          # pixel-space conditioning: 8x the 8x8 latent grid
+    out = {"in_cond": cond}
+    with torch.no_grad():
+        m = ref_ctrl.ControlNetSDVModel(**kw, conditioning_channels=3, conditioning_embedding_out_channels=(16, 32, 96, 256))
+        ou.init_weights_(m, WSEED + 5)                       # also fills the zero-initialised convolutions
+        o = oc.ControlNetSDVModel(TINY)
+        o.load_state_dict(m.state_dict())                    # name-for-name identical parameter tree
+        out["checksum"] = torch.tensor(checksum(m), dtype=torch.float64)
+        down, mid = m(inp["sample"], inp["t"], inp["enc"], inp["ids"], controlnet_cond=cond, return_dict=False,
+                      conditioning_scale=0.75)
+        for i, d in enumerate(down):
+            out[f"down_{i}"] = d
+        out["mid"] = mid
+        out["cond_embedding"] = m.controlnet_cond_embedding(cond)
+        down0, mid0 = m(inp["sample"], inp["t"], inp["enc"], inp["ids"], controlnet_cond=None, return_dict=False)
+        out["nocond_down_3"], out["nocond_mid"] = down0[3], mid0
+        # the residuals through the reference's UNet (pipeline_..._controlnet.py:582-607)
+        u = ref_stock.UNetSpatioTemporalConditionControlNetModel(**kw)
+        ou.init_weights_(u, WSEED)
+        out["unet_out"] = u(inp["sample"], inp["t"], inp["enc"], down_block_additional_residuals=down,
+                            mid_block_additional_residual=mid, added_time_ids=inp["ids"], return_dict=False)[0]
+    for k, v in inp.items():
+        out["in_" + k] = v
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "controlnet.safetensors"))
+    print("controlnet: %d down residuals, mid std %.4f, cond-embedding std %.4f, unet std %.4f" % (
+        len(down), mid.std(), out["cond_embedding"].std(), out["unet_out"].std()))
 
 
 # ------------------------------------------------------------------------------------------------ 3. patch hooks
@@ -505,6 +545,9 @@ def main():
                          "models.unet_spatio_temporal_condition_controlnet")
     ref_lk = load_ref("models/unet_spatio_temporal_condition.py", "models.unet_spatio_temporal_condition")
     gen_unet(ref_stock, ref_lk)
+    sys.modules["diffusers.models"].UNetSpatioTemporalConditionModel = ref_lk.UNetSpatioTemporalConditionModel
+    ref_ctrl = load_ref("models/controlnet_sdv.py", "models.controlnet_sdv")
+    gen_controlnet(ref_ctrl, ref_stock)
     _mod("patch")
     load_ref("patch/utils.py", "patch.utils")
     patch_mod = load_ref("patch/patch.py", "patch.patch")

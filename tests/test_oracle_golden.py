@@ -112,6 +112,36 @@ def test_structural_parameter_count():
     assert sum(p.numel() for p in b.parameters()) - na == 726_796
 
 
+# ------------------------------------------------------------------------------------------------ ControlNet (8f rank 1)
+def test_controlnet_encoder(golden_dir):
+    """models/controlnet_sdv.py: conditioning embedding, encoder, zero convolutions, conditioning_scale, and the
+    residuals through the stock UNet - against the reference's own classes"""
+    from oracle import controlnet as oc
+    g = load_file(os.path.join(golden_dir, "controlnet.safetensors"))
+    c = ou.init_weights_(oc.ControlNetSDVModel(ou.TINY_CONFIG), WSEED + 5)
+    assert abs(float(sum(p.double().abs().sum() for p in c.parameters())) - float(g["checksum"])) < 1e-6
+    with torch.no_grad():
+        down, mid = c(g["in_sample"], g["in_t"], g["in_enc"], g["in_ids"], controlnet_cond=g["in_cond"],
+                      return_dict=False, conditioning_scale=0.75)
+        assert len(down) == 12
+        for i, d in enumerate(down):
+            torch.testing.assert_close(d, g[f"down_{i}"], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(mid, g["mid"], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(c.controlnet_cond_embedding(g["in_cond"]), g["cond_embedding"], rtol=1e-5, atol=1e-6)
+        down0, mid0 = c(g["in_sample"], g["in_t"], g["in_enc"], g["in_ids"], return_dict=False)
+        torch.testing.assert_close(down0[3], g["nocond_down_3"], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(mid0, g["nocond_mid"], rtol=1e-4, atol=1e-4)
+        u = ou.init_weights_(ou.UNetSpatioTemporalConditionControlNetModel(ou.TINY_CONFIG), WSEED)
+        y = u(g["in_sample"], g["in_t"], g["in_enc"], down_block_additional_residuals=down,
+              mid_block_additional_residual=mid, added_time_ids=g["in_ids"], return_dict=False)[0]
+        torch.testing.assert_close(y, g["unet_out"], rtol=1e-4, atol=1e-4)
+    # fresh construction: the zero convolutions make every residual exactly zero
+    z = oc.ControlNetSDVModel(ou.TINY_CONFIG)
+    with torch.no_grad():
+        dz, mz = z(g["in_sample"], g["in_t"], g["in_enc"], g["in_ids"], controlnet_cond=g["in_cond"], return_dict=False)
+    assert all(float(d.abs().max()) == 0.0 for d in dz) and float(mz.abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------ patch hooks (a14)
 class _Holder(torch.nn.Module):
     def __init__(self):
