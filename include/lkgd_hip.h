@@ -218,6 +218,16 @@ typedef struct lkgd_fsm_desc {
 } lkgd_fsm_desc;
 int lkgd_fsm_rows(const lkgd_fsm_desc* desc, lkgd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * 10. Direct 3x3 convolution (pad 1, stride 1 or 2) for small channel counts, channels-last fp16, optional SiLU:
+ *     the conditioning-embedding stack of the ControlNet-SVD encoder (models/controlnet_sdv.py:64-119).
+ *     in [nimg*Hin*Win, ldi] (Cin % 8 == 0 channels used), w [Cout][3][3][Cin] fp16, bias fp32 [Cout] or NULL,
+ *     out [nimg*Hout*Wout, ldo], Hout = (Hin-1)/stride + 1; Cout % 16 == 0.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_conv3x3_small(const void* in, int32_t Cin, int32_t ldi, const void* w, const float* bias, void* out,
+                       int32_t Cout, int32_t ldo, int64_t nimg, int32_t Hin, int32_t Win, int32_t stride,
+                       int32_t silu, lkgd_stream_t stream);
+
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
 

@@ -316,6 +316,19 @@ def fsm_rows(a: torch.Tensor, out: torch.Tensor, *, pairs: int, HW: int, C_: int
     return out
 
 
+def conv3x3_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], nimg: int, Hin: int, Win: int,
+                  stride: int = 1, silu: bool = True) -> torch.Tensor:
+    """direct 3x3 convolution for small channel counts (include/lkgd_hip.h section 10); x [nimg*Hin*Win, Cin] tokens,
+    w [Cout, 3, 3, Cin] fp16 -> [nimg*Hout*Wout, Cout]"""
+    _req(x, torch.float16, "x"); _req(w, torch.float16, "w")
+    cout, cin = w.shape[0], w.shape[3]
+    Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    out = torch.empty(nimg * Hout * Wout, cout, dtype=torch.float16, device=x.device)
+    check(_lib.lib().lkgd_conv3x3_small(x.data_ptr(), cin, _ld(x), w.data_ptr(), _ptr(bias), out.data_ptr(), cout,
+                                        _ld(out), nimg, Hin, Win, stride, int(silu), _stream()), "lkgd_conv3x3_small")
+    return out
+
+
 def scale(x: torch.Tensor, s: float) -> torch.Tensor:
     _req(x, torch.float16, "x")
     x = x.contiguous()

@@ -812,6 +812,8 @@ def get_up_block(t, num_layers, in_channels, out_channels, prev_output_channel, 
 
 # ----------------------------------------------------------------------------------------------- top level
 class _UNetBase(nn.Module):
+    _encoder_only = False      # lkgd_amd.controlnet: conv_in, embeddings, down blocks and mid block only
+
     def __init__(self, config: Optional[UNetConfig] = None, **kw):
         super().__init__()
         cfg = config if config is not None else UNetConfig(**kw)
@@ -838,7 +840,8 @@ class _UNetBase(nn.Module):
         self.time_embedding = TimestepEmbedding(boc[0], ted)
         self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, ted)
         self.down_blocks = nn.ModuleList()
-        self.up_blocks = nn.ModuleList()
+        if not self._encoder_only:
+            self.up_blocks = nn.ModuleList()
         out_ch = boc[0]
         for i, t in enumerate(cfg.down_block_types):
             in_ch, out_ch = out_ch, boc[i]
@@ -847,6 +850,11 @@ class _UNetBase(nn.Module):
         self._init_extra(cfg)
         self.mid_block = UNetMidBlockSpatioTemporal(boc[-1], ted, transformer_layers_per_block=tlpb[-1],
                                                     num_attention_heads=heads[-1], cross_attention_dim=cross[-1])
+        self._pk = None
+        self._temb_reg: List[nn.Linear] = []
+        self._cross_reg: List[Attention] = []
+        if self._encoder_only:
+            return
         rboc, rheads = list(reversed(boc)), list(reversed(heads))
         rlpb, rcross, rtlpb = list(reversed(lpb)), list(reversed(cross)), list(reversed(tlpb))
         out_ch = rboc[0]
@@ -860,11 +868,11 @@ class _UNetBase(nn.Module):
         self.conv_norm_out = nn.GroupNorm(32, boc[0], eps=1e-5)
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)
-        self._pk = None
-        self._temb_reg: List[nn.Linear] = []
-        self._cross_reg: List[Attention] = []
 
     def _init_extra(self, cfg):
+        pass
+
+    def _pack_extra(self, pk):
         pass
 
     # ---- reference API surface -----------------------------------------------------------------
@@ -929,14 +937,16 @@ class _UNetBase(nn.Module):
         self._temb_reg, self._cross_reg = [], []
         self.time_embedding.pack()
         self.add_embedding.pack()
-        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+        for blk in list(self.down_blocks) + [self.mid_block] + ([] if self._encoder_only else list(self.up_blocks)):
             blk.pack(self)
         pk = SimpleNamespace()
         pk.w_in = pack_conv3x3_c8(self.conv_in.weight.detach())
         pk.b_in = _f32(self.conv_in.bias)
-        pk.gn_out = (_f32(self.conv_norm_out.weight), _f32(self.conv_norm_out.bias))
-        pk.w_out = pack_conv3x3(self.conv_out.weight.detach())
-        pk.b_out = _f32(self.conv_out.bias)
+        if not self._encoder_only:
+            pk.gn_out = (_f32(self.conv_norm_out.weight), _f32(self.conv_norm_out.bias))
+            pk.w_out = pack_conv3x3(self.conv_out.weight.detach())
+            pk.b_out = _f32(self.conv_out.bias)
+        self._pack_extra(pk)
         # all time_emb_proj layers of the model as ONE [sum C, 1280] GEMM per step
         pk.w_temb = torch.cat([pack_linear(l.weight) for l in self._temb_reg], dim=0).contiguous()
         pk.b_temb = torch.cat([_f32(l.bias) for l in self._temb_reg]).contiguous()
@@ -1022,6 +1032,10 @@ class _UNetBase(nn.Module):
                                    down_block_additional_residuals, mid_block_additional_residual)
 
     def _res_tokens(self, add: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        if add.dim() == 2:          # already a channels-last token matrix (lkgd_amd.controlnet's token-level output)
+            if add.shape != like.shape or add.dtype != torch.float16 or add.device != like.device:
+                raise ValueError(f"additional residual tokens {tuple(add.shape)} do not match skip {tuple(like.shape)}")
+            return add
         a = add.to(device=like.device, dtype=torch.float16).contiguous()
         t = ops.nchw_to_tokens(a)
         if t.shape != like.shape:

@@ -123,3 +123,55 @@ def test_no_cpu_path():
     m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
     with pytest.raises(LkgdHipError):
         m(torch.zeros(1, 2, 8, 8, 8), 1.0, torch.zeros(1, 1, 1024), added_time_ids=torch.zeros(1, 3))
+
+
+def test_controlnet_encoder_vs_reference_golden(golden_dir):
+    """ControlNet-SVD encoder on the HIP path: conditioning embedding (small-channel direct convs +
+    implicit-GEMM conv_out fused with the add), encoder, zero convolutions with conditioning_scale, and the residuals
+    fed to the UNet as token matrices - against the outputs of the reference's own classes"""
+    import os
+    from safetensors.torch import load_file
+    from lkgd_amd import controlnet as pc
+    from lkgd_amd import unet as pu
+    from oracle import controlnet as oc
+    from oracle import unet as ou
+    g = load_file(os.path.join(golden_dir, "controlnet.safetensors"))
+    oc_model = ou.init_weights_(oc.ControlNetSDVModel(ou.TINY_CONFIG), WSEED + 5)
+    m = pc.ControlNetSDVModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    m.load_state_dict(oc_model.state_dict(), strict=True)        # the reference's key names
+    m = m.half().to(DEV)
+    dev = lambda k: g[k].to(DEV)
+    down, mid = m(dev("in_sample").half(), dev("in_t"), dev("in_enc").half(), dev("in_ids"),
+                  controlnet_cond=dev("in_cond").half(), return_dict=False, conditioning_scale=0.75)
+    assert len(down) == 12
+    tol = lambda r: dict(rel_tol=1.5e-2, abs_tol=0.03 * float(r.abs().max()) + 5e-2)   # residuals are not unit-variance
+    for i, d in enumerate(down):
+        assert d.shape == g[f"down_{i}"].shape
+        _gate(d, g[f"down_{i}"], f"controlnet down {i}", **tol(g[f"down_{i}"]))
+    _gate(mid, g["mid"], "controlnet mid", **tol(g["mid"]))
+    # without conditioning; cache of the conditioning embedding is keyed on the tensor
+    down0, mid0 = m(dev("in_sample").half(), dev("in_t"), dev("in_enc").half(), dev("in_ids"), return_dict=False)
+    _gate(down0[3], g["nocond_down_3"], "controlnet down 3, no cond", **tol(g["nocond_down_3"]))
+    _gate(mid0, g["nocond_mid"], "controlnet mid, no cond", **tol(g["nocond_mid"]))
+    # residuals into the UNet, as token matrices (the in-loop path) and as NCHW tensors (the reference's API)
+    u_o = ou.init_weights_(ou.UNetSpatioTemporalConditionControlNetModel(ou.TINY_CONFIG), WSEED)
+    u = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    u.load_state_dict(u_o.state_dict(), strict=True)
+    u = u.half().to(DEV)
+    y = u(dev("in_sample").half(), dev("in_t"), dev("in_enc").half(), down_block_additional_residuals=down,
+          mid_block_additional_residual=mid, added_time_ids=dev("in_ids"), return_dict=False)[0]
+    _gate(y, g["unet_out"], "unet with controlnet residuals (NCHW)")
+    from lkgd_amd import ops
+    x = dev("in_sample").half()
+    B, F, C, H, W = x.shape
+    tok = ops.nchw_to_tokens(x.reshape(B * F, C, H, W).contiguous())
+    dt, mt, _ = m.forward_tokens(tok, B, F, H, W, dev("in_t"), dev("in_enc").half(), dev("in_ids"),
+                                 dev("in_cond").half(), 0.75)
+    out_tok, ctx = u.forward_tokens(tok, B, F, H, W, dev("in_t"), dev("in_enc").half(), dev("in_ids"), dt, mt)
+    y2 = ops.tokens_to_nchw(out_tok, B * F, 4, H, W).reshape(B, F, 4, H, W)
+    assert torch.equal(y2, y)
+    # zero-initialised module: all residuals exactly zero
+    z = pc.ControlNetSDVModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__)).half().to(DEV)
+    dz, mz = z(dev("in_sample").half(), dev("in_t"), dev("in_enc").half(), dev("in_ids"),
+               controlnet_cond=dev("in_cond").half(), return_dict=False)
+    assert all(float(d.abs().max()) == 0.0 for d in dz) and float(mz.abs().max()) == 0.0
