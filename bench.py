@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="tiny UNet config (plumbing checks only; not a valid number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--controlnet", action="store_true",
+                    help="also run the ControlNet-SVD encoder every step (SURVEY.md 8f rank 1; not the headline workload)")
     return ap.parse_args()
 
 
@@ -144,6 +146,20 @@ def main():
     unet = build_unet(dev, args.tiny)
     pipe = StableVideoDiffusionPipeline(unet=unet)
     lat0, img, emb, ids = synthetic_inputs(dev, args.frames, h, w)
+    ctrl_cond = None
+    if args.controlnet:
+        if distributed:
+            raise SystemExit("--controlnet is a single-GPU option")
+        from lkgd_amd import controlnet as pc
+        from lkgd_amd import unet as pu
+        with torch.device("meta"):
+            cn = pc.ControlNetSDVModel(pu.UNetConfig(**{k: v for k, v in unet.config.__dict__.items()
+                                                        if k in pu.UNetConfig.__dataclass_fields__}))
+        cn = cn.to(torch.float16).to_empty(device=dev)
+        pu.init_synthetic_weights_(cn, seed=1)
+        pipe.controlnet = cn
+        ctrl_cond = (2.0 * torch.rand(1, args.frames, 3, args.height, args.width,
+                                      generator=torch.Generator().manual_seed(12348)) - 1.0).half().to(dev).repeat(2, 1, 1, 1, 1)
     pipe.scheduler.set_timesteps(args.inference_steps)
     sigma0 = float(pipe.scheduler.init_noise_sigma)
 
@@ -155,7 +171,8 @@ def main():
             return runner.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0)
     else:
         def one_clip():
-            return pipe.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0)
+            return pipe.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0,
+                                controlnet_condition=ctrl_cond)
 
     def barrier():
         if distributed:
@@ -212,7 +229,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"SVD {args.frames} frames x {args.height}x{args.width}, "
                                    f"{args.inference_steps} Euler steps, CFG 1.0->3.0, single clip, "
-                                   "vanilla pipeline_stable_video_diffusion_trans loop (configs[1])"
+                                   + ("ControlNet pipeline loop (pipeline_stable_video_diffusion_controlnet, NOT the headline)"
+                                      if args.controlnet else
+                                      "vanilla pipeline_stable_video_diffusion_trans loop (configs[1])")
                                    + (" [TINY UNET - INVALID]" if args.tiny else ""),
                        "unet": "random-init SVD shapes (320,640,1280,1280), heads (5,10,20,20), 1.52 B params",
                        "parallelism": "single GPU" if world == 1 else f"cfg x frame shards over {world} GPUs"},

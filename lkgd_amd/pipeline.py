@@ -41,8 +41,10 @@ class StableVideoDiffusionPipeline:
     _callback_tensor_inputs = ["latents"]
 
     def __init__(self, vae=None, image_encoder=None, unet=None, scheduler: Optional[EulerDiscreteScheduler] = None,
-                 feature_extractor=None):
+                 feature_extractor=None, controlnet=None):
         self.vae, self.image_encoder, self.unet = vae, image_encoder, unet
+        #: optional lkgd_amd.controlnet.ControlNetSDVModel (reference pipeline_stable_video_diffusion_controlnet.py:156-178)
+        self.controlnet = controlnet
         self.scheduler = scheduler if scheduler is not None else EulerDiscreteScheduler.from_svd_config()
         self.feature_extractor = feature_extractor
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
@@ -155,9 +157,12 @@ class StableVideoDiffusionPipeline:
                 added_time_ids: torch.Tensor, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
                 max_guidance_scale: float = 3.0, domain_features: Optional[torch.Tensor] = None,
                 flow_features: Optional[torch.Tensor] = None, callback_on_step_end: Optional[Callable] = None,
-                callback_on_step_end_tensor_inputs: List[str] = ["latents"]) -> torch.Tensor:
+                callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+                controlnet_condition: Optional[torch.Tensor] = None, controlnet_cond_scale: float = 1.0) -> torch.Tensor:
         """Reference loop :503-640.  ``latents`` [B,F,4,h,w] already scaled by init_noise_sigma (fp16 or fp32, updated
-        in place and returned); ``image_latents`` [cfg*B,F,4,h,w] fp16; ``image_embeddings`` [cfg*B,1,1024]."""
+        in place and returned); ``image_latents`` [cfg*B,F,4,h,w] fp16; ``image_embeddings`` [cfg*B,1,1024].
+        ``controlnet_condition`` [cfg*B,F,3,8h,8w] (already preprocessed and duplicated for CFG) runs ``self.controlnet``
+        before the UNet every step and feeds its residuals in (pipeline_stable_video_diffusion_controlnet.py:582-607)."""
         unet, sch = self.unet, self.scheduler
         dev = unet.device
         B, F, _, H, W = latents.shape
@@ -180,7 +185,14 @@ class StableVideoDiffusionPipeline:
         vpred = sch.config.prediction_type == "v_prediction"
         from . import patch as _patch
         _patch.set_joint_attention(unet, enable=True)           # reference :555 (no-op unless the model is patched)
-        fwd = self._graphed_forward(cfg * B, F, H, W, enc, ids) if self.use_hip_graph else None
+        ctrl = None
+        if controlnet_condition is not None:
+            if self.controlnet is None:
+                raise LkgdHipError("controlnet_condition given but the pipeline has no controlnet")
+            if controlnet_condition.shape[0] != cfg * B:
+                raise ValueError("controlnet_condition must carry cfg*batch entries")
+            ctrl = controlnet_condition.to(device=dev, dtype=torch.float16).contiguous()
+        fwd = self._graphed_forward(cfg * B, F, H, W, enc, ids) if (self.use_hip_graph and ctrl is None) else None
         for i, t in enumerate(sch.timesteps_host):
             sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
             if fwd is not None:
@@ -188,7 +200,11 @@ class StableVideoDiffusionPipeline:
                 noise_tok = fwd.run(t)
             else:
                 tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)
-                noise_tok, _ = unet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids)
+                down = mid = None
+                if ctrl is not None:      # residuals stay channels-last token matrices between the two models
+                    down, mid, _ = self.controlnet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids, ctrl,
+                                                                  controlnet_cond_scale)
+                noise_tok, _ = unet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids, down, mid)
             ops.cfg_euler_step(noise_tok, latents, guidance_dev, cfg, sigma, sigma_next, v_prediction=vpred)
             if callback_on_step_end is not None:
                 kw = {k: {"latents": latents}[k] for k in callback_on_step_end_tensor_inputs}
@@ -245,7 +261,9 @@ class StableVideoDiffusionPipeline:
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"], return_dict: bool = True,
                  # extensions (keyword-only in practice; defaults keep the reference call sites unchanged)
                  image_embeddings: Optional[torch.Tensor] = None, image_latents: Optional[torch.Tensor] = None,
-                 domain_features: Optional[torch.Tensor] = None, flow_features: Optional[torch.Tensor] = None):
+                 domain_features: Optional[torch.Tensor] = None, flow_features: Optional[torch.Tensor] = None,
+                 # pipeline_stable_video_diffusion_controlnet.py:356-380: a [F,3,H,W] (or [1,F,3,H,W]) tensor in [0,1]
+                 controlnet_condition: Optional[torch.Tensor] = None, controlnet_cond_scale: float = 1.0):
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
@@ -281,9 +299,19 @@ class StableVideoDiffusionPipeline:
         self.scheduler.set_timesteps(num_inference_steps, device=None)
         lat = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, self.unet.config.in_channels,
                                    height, width, torch.float16, device, generator, latents)
+        if controlnet_condition is not None:
+            # reference :546-550: VaeImageProcessor.preprocess ([0,1] -> [-1,1]), add the batch axis, duplicate for CFG
+            cc = controlnet_condition
+            if not isinstance(cc, torch.Tensor):
+                raise NotImplementedError("PIL conditioning needs the VaeImageProcessor boundary stage (SURVEY.md 8f rank 2)")
+            cc = 2.0 * cc.to(device) - 1.0
+            if cc.dim() == 4:
+                cc = cc.unsqueeze(0)
+            controlnet_condition = torch.cat([cc] * 2) if cfg else cc
         lat = self.denoise(lat, image_latents.contiguous(), image_embeddings, added_time_ids, num_inference_steps,
                            min_guidance_scale, max_guidance_scale, domain_features, flow_features,
-                           callback_on_step_end, callback_on_step_end_tensor_inputs)
+                           callback_on_step_end, callback_on_step_end_tensor_inputs, controlnet_condition,
+                           controlnet_cond_scale)
         if output_type != "latent":
             frames = self.decode_latents(lat, num_frames, decode_chunk_size)
             if output_type == "pt":

@@ -23,7 +23,8 @@ def denoise(unet: Callable, scheduler: EulerDiscreteOracle, latents: torch.Tenso
             image_embeddings: torch.Tensor, added_time_ids: torch.Tensor, num_inference_steps: int,
             min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0,
             domain_features: Optional[torch.Tensor] = None, flow_features: Optional[torch.Tensor] = None,
-            callback: Optional[Callable] = None) -> torch.Tensor:
+            callback: Optional[Callable] = None, controlnet: Optional[Callable] = None,
+            controlnet_condition: Optional[torch.Tensor] = None, controlnet_cond_scale: float = 1.0) -> torch.Tensor:
     """``latents``: unit-variance noise [B,F,4,h,w] (scaled by init_noise_sigma here, :330); ``image_latents``
     [2B or B,F,4,h,w] already CFG-concatenated and repeated over frames (:221,:488); ``image_embeddings`` [2B,1,1024]."""
     do_cfg = max_guidance_scale > 1
@@ -36,7 +37,14 @@ def denoise(unet: Callable, scheduler: EulerDiscreteOracle, latents: torch.Tenso
         x = torch.cat([latents] * 2) if do_cfg else latents
         x = scheduler.scale_model_input(x, t)
         x = torch.cat([x, image_latents], dim=2)
-        if domain_features is not None:
+        if controlnet is not None:
+            # /root/reference/pipeline/pipeline_stable_video_diffusion_controlnet.py:582-607
+            down, mid = controlnet(x, t, encoder_hidden_states=image_embeddings, controlnet_cond=controlnet_condition,
+                                   added_time_ids=added_time_ids, conditioning_scale=controlnet_cond_scale,
+                                   guess_mode=False, return_dict=False)
+            noise_pred = unet(x, t, encoder_hidden_states=image_embeddings, down_block_additional_residuals=down,
+                              mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
+        elif domain_features is not None:
             noise_pred = unet(x, t, image_embeddings, domain_features, flow_features,
                               added_time_ids=added_time_ids, return_dict=False)[0]
         else:

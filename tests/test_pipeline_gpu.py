@@ -378,3 +378,45 @@ def test_patch_joint_post_variants_vs_reference_golden(golden_dir, post):
     posemb = torch.zeros(frames, C, dtype=torch.float16, device=DEV)
     got = h.temporal.run(ctx, x.reshape(-1, C).half().to(DEV), posemb, 0.0, (frames * S, S, S, 4 * S))
     assert _rel(got.reshape(4 * frames, S, C), g[f"{post}.temporal_joint"]) < 5e-3
+
+
+def test_controlnet_loop_vs_oracle():
+    """the ControlNet pipeline loop (pipeline_stable_video_diffusion_controlnet.py:582-607): ControlNet encoder before the
+    UNet every step, residuals handed over as token matrices"""
+    from lkgd_amd import controlnet as pc
+    from lkgd_amd import unet as pu
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+    from oracle import controlnet as oc
+    from oracle import unet as ou
+    from oracle.loop import denoise
+    from oracle.scheduler import EulerDiscreteOracle, SchedulerConfig
+    o, m = _unet(seed=81)
+    oc_m = ou.init_weights_(oc.ControlNetSDVModel(ou.TINY_CONFIG), 82, gain=0.5)
+    with torch.no_grad():
+        for p_ in list(o.parameters()) + list(oc_m.parameters()):
+            p_.copy_(p_.half().float())
+    m.load_state_dict(o.state_dict())
+    c = pc.ControlNetSDVModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    c.load_state_dict(oc_m.state_dict())
+    c = c.half().to(DEV)
+    g = torch.Generator().manual_seed(83)
+    B, F, H, W = 1, 4, 8, 8
+    lat0 = torch.randn(B, F, 4, H, W, generator=g)
+    img = torch.randn(1, 4, H, W, generator=g) * 0.18215
+    img = torch.cat([torch.zeros_like(img), img]).unsqueeze(1).repeat(1, F, 1, 1, 1)
+    enc = torch.cat([torch.zeros(1, 1, 1024), torch.randn(1, 1, 1024, generator=g)])
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    cond = (2.0 * torch.rand(1, F, 3, 8 * H, 8 * W, generator=g) - 1.0).repeat(2, 1, 1, 1, 1)
+    sch = EulerDiscreteOracle(SchedulerConfig())
+    with torch.no_grad():
+        ref = denoise(o, sch, lat0, img.half().float(), enc.half().float(), ids, 2, controlnet=oc_m,
+                      controlnet_condition=cond.half().float(), controlnet_cond_scale=0.8)
+    pipe = StableVideoDiffusionPipeline(unet=m, controlnet=c)
+    pipe.scheduler.set_timesteps(2)
+    lat = (lat0 * float(pipe.scheduler.init_noise_sigma)).half().to(DEV)
+    got = pipe.denoise(lat, img.half().to(DEV), enc.half().to(DEV), ids.to(DEV), 2,
+                       controlnet_condition=cond.half().to(DEV), controlnet_cond_scale=0.8)
+    assert _rel(got, ref) < 2e-2
+    plain = pipe.denoise((lat0 * float(pipe.scheduler.init_noise_sigma)).half().to(DEV), img.half().to(DEV),
+                         enc.half().to(DEV), ids.to(DEV), 2)
+    assert _rel(plain, ref) > 1e-3          # the ControlNet branch really changes the result
