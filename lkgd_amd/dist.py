@@ -88,26 +88,43 @@ def all_gather_into(buf: torch.Tensor, send: torch.Tensor, group=None) -> None:
     buf.copy_(hb)
 
 
+def _step(f) -> None:
+    """run a host-side exchange step now; under lkgd_amd.replay recording also make it part of the plan"""
+    from . import ops
+    f()
+    if ops.PLAN is not None:
+        ops.PLAN.python(f)
+
+
 def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
-    """local [f_local, ...] -> [num_frames, ...] over the frame group (padded equal-count all-gather + compaction)."""
+    """local [f_local, ...] -> [num_frames, ...] over the frame group (padded equal-count all-gather + compaction).
+    Buffers are allocated outside the replayable steps, so a recorded plan re-runs only copies and the collective."""
     if plan.frame_shards == 1:
         return local
     fmax = plan.f_max
     if local.shape[0] != plan.f_local:
         raise ValueError("local frame count does not match the plan")
+    if not local.is_contiguous():
+        raise ValueError("gather_frames needs a contiguous slice")
     send = local
     if plan.f_local < fmax:
         send = torch.zeros((fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        send[:plan.f_local].copy_(local)
+        head = send[:plan.f_local]
+        _step(lambda: head.copy_(local))
     buf = torch.empty((plan.frame_shards * fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    all_gather_into(buf, send.contiguous(), group)
+    _step(lambda: all_gather_into(buf, send, group))
     if all(s == fmax for s in plan.splits):
         return buf
     out = torch.empty((plan.num_frames,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    f = 0
+    pairs, f = [], 0
     for j, n in enumerate(plan.splits):
-        out[f:f + n].copy_(buf[j * fmax:j * fmax + n])
+        pairs.append((out[f:f + n], buf[j * fmax:j * fmax + n]))
         f += n
+
+    def compact():
+        for dst, src in pairs:
+            dst.copy_(src)
+    _step(compact)
     return out
 
 
@@ -115,9 +132,11 @@ def allreduce_sums(sums: torch.Tensor, plan: ShardPlan, group=None) -> torch.Ten
     """sum of the GroupNorm partial sums over the frame group (fp32, a few hundred bytes)"""
     if plan.frame_shards > 1:
         if _backend(group) == "nccl" or not sums.is_cuda:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            _step(lambda: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group))
         else:
-            h = sums.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
-            sums.copy_(h)
+            def via_host():
+                h = sums.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                sums.copy_(h)
+            _step(via_host)
     return sums

@@ -15,12 +15,13 @@ Correctness notes
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import ops, replay
 from ._lib import LkgdHipError
 from .dist import ShardPlan, all_gather_into, allreduce_sums, gather_frames, make_plan
 
@@ -61,6 +62,9 @@ class DistDenoiser:
             if c == self.plan.cfg_index:
                 self.frame_group = g
         self.shard = ShardInfo(self.plan, self.frame_group)
+        #: replay the step's UNet forward from a recorded launch list (lkgd_amd/replay.py); a frame-sharded rank has
+        #: only ~1/8 of the device work per forward and would otherwise wait on the Python module walk
+        self.use_replay = os.environ.get("LKGD_NO_REPLAY", "0") != "1"
 
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, image_embeddings: torch.Tensor,
@@ -96,15 +100,34 @@ class DistDenoiser:
         send = torch.zeros(fmax * HW * b_local, 4, dtype=torch.float16, device=dev)
         buf = torch.empty(plan.world * fmax * HW * b_local, 4, dtype=torch.float16, device=dev)
         noise_full = torch.empty(cfg * F * HW, 4, dtype=torch.float16, device=dev)
+        # step-invariant addresses for everything the forward reads, so its launch list can be replayed
+        tok = torch.empty(cfg * F * HW, 8, dtype=torch.float16, device=dev)
+        t_dev = torch.zeros(b_local, dtype=torch.float32, device=dev)
+        ids_local = ids_local.to(torch.float32).contiguous()
+        enc = enc.to(torch.float16).contiguous()
+        if plan.cfg_groups == 2:
+            r0 = (plan.cfg_index * F + f0) * HW
+            tok_local, pick = tok[r0:r0 + fl * HW], None
+        else:
+            tok_local = torch.empty(cfg * fl * HW, 8, dtype=torch.float16, device=dev)
+            pick = (tok_local.reshape(cfg, fl, HW, 8), tok.reshape(cfg, F, HW, 8)[:, f0:f0 + fl])
+        recorded = None
         for i, t in enumerate(sch.timesteps_host):
             sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
-            tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)        # [cfg*F*HW, 8], replicated
-            if plan.cfg_groups == 2:
-                r0 = (plan.cfg_index * F + f0) * HW
-                tok_local = tok[r0:r0 + fl * HW]
+            ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=tok)     # [cfg*F*HW, 8], replicated
+            if pick is not None:
+                pick[0].copy_(pick[1])
+            t_dev.fill_(float(t))
+            if recorded is not None:
+                noise_local = recorded.run(ops.GEMM_EVENTS)
+            elif self.use_replay:
+                with replay.record() as recorded:           # the first step runs for real and is recorded
+                    recorded.result, _ = unet.forward_tokens(tok_local, b_local, fl, H, W, t_dev, enc, ids_local,
+                                                             shard=self.shard)
+                noise_local = recorded.result
             else:
-                tok_local = tok.reshape(cfg, F, HW, 8)[:, f0:f0 + fl].reshape(-1, 8).contiguous()
-            noise_local, _ = unet.forward_tokens(tok_local, b_local, fl, H, W, t, enc, ids_local, shard=self.shard)
+                noise_local, _ = unet.forward_tokens(tok_local, b_local, fl, H, W, t_dev, enc, ids_local,
+                                                     shard=self.shard)
             # ---- exchange the noise prediction over all ranks (padded equal counts), compact, replicate the update
             if plan.cfg_groups == 2:
                 send[:fl * HW].copy_(noise_local)

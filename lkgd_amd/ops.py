@@ -19,6 +19,23 @@ _zeros = {}
 #: is appended (bench.py's live roofline measurement); None = off
 GEMM_EVENTS = None
 
+#: lkgd_amd.replay.Plan while a kernel sequence is being recorded (every launch below is then also appended to it)
+PLAN = None
+_REC = {}
+
+
+def _L():
+    """the C-ABI library, or its recording stand-in"""
+    real = _lib.lib()
+    if PLAN is None:
+        return real
+    from .replay import _RecordingLib
+    rec = _REC.get(id(PLAN))
+    if rec is None:
+        _REC.clear()
+        rec = _REC[id(PLAN)] = _RecordingLib(real, PLAN)
+    return rec
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -108,11 +125,11 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     if ev is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s_ev.record()
-        check(_lib.lib().lkgd_gemm_f16(C.byref(d), _stream()), "lkgd_gemm_f16")
+        check(_L().lkgd_gemm_f16(C.byref(d), _stream()), "lkgd_gemm_f16")
         e_ev.record()
         ev.append((s_ev, e_ev, 2.0 * M * N * (72 if mode == A_CONV3X3_C8 else K)))
         return out
-    check(_lib.lib().lkgd_gemm_f16(C.byref(d), _stream()), "lkgd_gemm_f16")
+    check(_L().lkgd_gemm_f16(C.byref(d), _stream()), "lkgd_gemm_f16")
     return out
 
 
@@ -121,7 +138,7 @@ def groupnorm_stats(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int,
     _req(x0, torch.float16, "x0")
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
-    L = _lib.lib()
+    L = _L()
     nchunks = L.lkgd_groupnorm_chunks(rows_per_sample, c0 + c1)
     partial = torch.empty(nsamples * nchunks * 64, dtype=torch.float32, device=x0.device)
     stats = torch.empty(nsamples, 32, 2, dtype=torch.float32, device=x0.device)
@@ -136,7 +153,7 @@ def groupnorm_sums(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, 
     _req(x0, torch.float16, "x0")
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
-    L = _lib.lib()
+    L = _L()
     nchunks = L.lkgd_groupnorm_chunks(rows_per_sample, c0 + c1)
     partial = torch.empty(nsamples * nchunks * 64, dtype=torch.float32, device=x0.device)
     sums = torch.empty(nsamples, 32, 2, dtype=torch.float32, device=x0.device)
@@ -149,7 +166,7 @@ def groupnorm_sums(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, 
 def groupnorm_finalize(sums: torch.Tensor, count_per_group: float, eps: float) -> torch.Tensor:
     _req(sums, torch.float32, "sums")
     stats = torch.empty_like(sums)
-    check(_lib.lib().lkgd_groupnorm_finalize(sums.data_ptr(), sums.shape[0], float(count_per_group), eps,
+    check(_L().lkgd_groupnorm_finalize(sums.data_ptr(), sums.shape[0], float(count_per_group), eps,
                                              stats.data_ptr(), _stream()), "lkgd_groupnorm_finalize")
     return stats
 
@@ -160,7 +177,7 @@ def groupnorm_apply(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int,
     _req(x0, torch.float16, "x0"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
-    check(_lib.lib().lkgd_groupnorm_apply(x0.data_ptr(), c0, _ld(x0), _ptr(x1), c1,
+    check(_L().lkgd_groupnorm_apply(x0.data_ptr(), c0, _ld(x0), _ptr(x1), c1,
                                           _ld(x1) if x1 is not None else 0, nsamples, rows_per_sample,
                                           stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0,
                                           out.data_ptr(), _ld(out), _stream()), "lkgd_groupnorm_apply")
@@ -186,7 +203,7 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     if out is None:
         out = torch.empty(T, C_, dtype=torch.float16, device=x.device)
     d1, m1, d2, md = rowmap if rowmap is not None else (1, 0, 1, 1)
-    check(_lib.lib().lkgd_layernorm(x.data_ptr(), _ld(x), T, C_, _ptr(gamma), _ptr(beta), eps,
+    check(_L().lkgd_layernorm(x.data_ptr(), _ld(x), T, C_, _ptr(gamma), _ptr(beta), eps,
                                     _ptr(rowbias), _ld(rowbias) if rowbias is not None else 0, d1, m1, d2, md,
                                     out.data_ptr(), _ld(out), _stream()), "lkgd_layernorm")
     return out
@@ -195,7 +212,7 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
 def attn_spatial(q, k, v, out, nbatch: int, S: int, heads: int, kv_batch_map: Optional[torch.Tensor] = None,
                  scale: float = 0.125):
     _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v")
-    check(_lib.lib().lkgd_attn_spatial(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
+    check(_L().lkgd_attn_spatial(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
                                        out.data_ptr(), _ld(out), nbatch, S, heads, _ptr(kv_batch_map), scale,
                                        _stream()), "lkgd_attn_spatial")
     return out
@@ -205,7 +222,7 @@ def attn_temporal(q, k, v, out, B: int, F: int, S: int, heads: int, kv_b_map: Op
                   scale: float = 0.125, Fq: Optional[int] = None):
     """F = key/value frames; Fq = query frames (defaults to F; smaller under frame sharding)"""
     _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v")
-    check(_lib.lib().lkgd_attn_temporal(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
+    check(_L().lkgd_attn_temporal(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
                                         out.data_ptr(), _ld(out), B, Fq if Fq is not None else F, F, S, heads,
                                         _ptr(kv_b_map), scale, _stream()),
           "lkgd_attn_temporal")
@@ -223,7 +240,7 @@ def prepare_unet_input(latents: torch.Tensor, image_latents: torch.Tensor, cfg: 
     assert image_latents.shape == (cfg * B, F, 4, H, W), image_latents.shape
     if out is None:
         out = torch.empty(cfg * B * F * H * W, 8, dtype=torch.float16, device=latents.device)
-    check(_lib.lib().lkgd_prepare_unet_input(latents.data_ptr(), int(latents.dtype == torch.float32),
+    check(_L().lkgd_prepare_unet_input(latents.data_ptr(), int(latents.dtype == torch.float32),
                                              image_latents.data_ptr(), B, F, H, W, cfg, sigma, out.data_ptr(),
                                              _stream()), "lkgd_prepare_unet_input")
     return out
@@ -235,7 +252,7 @@ def cfg_euler_step(noise_tokens: torch.Tensor, latents: torch.Tensor, guidance: 
     B, F, _, H, W = latents.shape
     _req(noise_tokens, torch.float16, "noise_tokens")
     assert latents.is_contiguous() and noise_tokens.is_contiguous()
-    check(_lib.lib().lkgd_cfg_euler_step(noise_tokens.data_ptr(), latents.data_ptr(),
+    check(_L().lkgd_cfg_euler_step(noise_tokens.data_ptr(), latents.data_ptr(),
                                          int(latents.dtype == torch.float32), _ptr(guidance), B, F, H, W, cfg, sigma,
                                          sigma_next, 1 if v_prediction else 0, _stream()), "lkgd_cfg_euler_step")
     return latents
@@ -244,7 +261,7 @@ def cfg_euler_step(noise_tokens: torch.Tensor, latents: torch.Tensor, guidance: 
 def tokens_to_nchw(tokens: torch.Tensor, N: int, C_: int, H: int, W: int) -> torch.Tensor:
     _req(tokens, torch.float16, "tokens")
     out = torch.empty(N, C_, H, W, dtype=torch.float16, device=tokens.device)
-    check(_lib.lib().lkgd_tokens_to_nchw(tokens.data_ptr(), _ld(tokens), N, C_, H * W, out.data_ptr(), _stream()),
+    check(_L().lkgd_tokens_to_nchw(tokens.data_ptr(), _ld(tokens), N, C_, H * W, out.data_ptr(), _stream()),
           "lkgd_tokens_to_nchw")
     return out
 
@@ -255,7 +272,7 @@ def nchw_to_tokens(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
     assert x.is_contiguous()
     if out is None:
         out = torch.empty(N * H * W, C_, dtype=torch.float16, device=x.device)
-    check(_lib.lib().lkgd_nchw_to_tokens(x.data_ptr(), N, C_, H * W, out.data_ptr(), _ld(out), _stream()),
+    check(_L().lkgd_nchw_to_tokens(x.data_ptr(), N, C_, H * W, out.data_ptr(), _ld(out), _stream()),
           "lkgd_nchw_to_tokens")
     return out
 
@@ -263,7 +280,7 @@ def nchw_to_tokens(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     _req(t, torch.float32, "t")
     out = torch.empty(t.numel(), dim, dtype=torch.float16, device=t.device)
-    check(_lib.lib().lkgd_timestep_embedding(t.data_ptr(), t.numel(), dim, out.data_ptr(), dim, _stream()),
+    check(_L().lkgd_timestep_embedding(t.data_ptr(), t.numel(), dim, out.data_ptr(), dim, _stream()),
           "lkgd_timestep_embedding")
     return out
 
@@ -271,14 +288,14 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
 def silu(x: torch.Tensor) -> torch.Tensor:
     _req(x, torch.float16, "x")
     y = torch.empty_like(x)
-    check(_lib.lib().lkgd_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "lkgd_silu")
+    check(_L().lkgd_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "lkgd_silu")
     return y
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _req(a, torch.float16, "a"); _req(b, torch.float16, "b")
     y = torch.empty_like(a)
-    check(_lib.lib().lkgd_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "lkgd_add")
+    check(_L().lkgd_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "lkgd_add")
     return y
 
 
@@ -312,7 +329,7 @@ def fsm_rows(a: torch.Tensor, out: torch.Tensor, *, pairs: int, HW: int, C_: int
             raise _lib.LkgdHipError("fsm_rows: CSR table sizes do not match pairs*HW / pairs*P")
         d.csr_off, d.csr_pt, d.gather_idx, d.vis = off.data_ptr(), pt.data_ptr(), gi.data_ptr(), vis.data_ptr()
         d.P = pt.numel() // pairs
-    check(_lib.lib().lkgd_fsm_rows(C.byref(d), _stream()), "lkgd_fsm_rows")
+    check(_L().lkgd_fsm_rows(C.byref(d), _stream()), "lkgd_fsm_rows")
     return out
 
 
@@ -324,7 +341,7 @@ def conv3x3_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     cout, cin = w.shape[0], w.shape[3]
     Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
     out = torch.empty(nimg * Hout * Wout, cout, dtype=torch.float16, device=x.device)
-    check(_lib.lib().lkgd_conv3x3_small(x.data_ptr(), cin, _ld(x), w.data_ptr(), _ptr(bias), out.data_ptr(), cout,
+    check(_L().lkgd_conv3x3_small(x.data_ptr(), cin, _ld(x), w.data_ptr(), _ptr(bias), out.data_ptr(), cout,
                                         _ld(out), nimg, Hin, Win, stride, int(silu), _stream()), "lkgd_conv3x3_small")
     return out
 
@@ -333,7 +350,7 @@ def scale(x: torch.Tensor, s: float) -> torch.Tensor:
     _req(x, torch.float16, "x")
     x = x.contiguous()
     y = torch.empty_like(x)
-    check(_lib.lib().lkgd_scale(x.data_ptr(), y.data_ptr(), x.numel(), s, _stream()), "lkgd_scale")
+    check(_L().lkgd_scale(x.data_ptr(), y.data_ptr(), x.numel(), s, _stream()), "lkgd_scale")
     return y
 
 
@@ -344,7 +361,7 @@ def euler_step(model_output: torch.Tensor, sample: torch.Tensor, sigma: float, s
         raise _lib.LkgdHipError("sample must be a GPU fp16/fp32 tensor")
     mo, sm = model_output.contiguous(), sample.contiguous()
     prev = torch.empty_like(mo)
-    check(_lib.lib().lkgd_euler_step(mo.data_ptr(), sm.data_ptr(), int(sm.dtype == torch.float32), prev.data_ptr(),
+    check(_L().lkgd_euler_step(mo.data_ptr(), sm.data_ptr(), int(sm.dtype == torch.float32), prev.data_ptr(),
                                      mo.numel(), sigma, sigma_next, 1 if v_prediction else 0, _stream()),
           "lkgd_euler_step")
     return prev

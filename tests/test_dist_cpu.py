@@ -58,6 +58,19 @@ def _worker(rank, world, port, frames, q):
         # fp16 payload, as the activations are
         h = gather_frames(local.half(), plan)
         ok = ok and torch.equal(h, full.half())
+        # recorded exchange steps (lkgd_amd/replay.py): new values in the same buffers, same plan
+        from lkgd_amd import replay
+        src = local.clone()
+        sums2 = torch.full((1, 32, 2), float(rank + 1))
+        with replay.record() as rec:
+            got2 = gather_frames(src, plan)
+            allreduce_sums(sums2, plan)
+        ok = ok and torch.equal(got2, full)
+        src.mul_(2.0)
+        sums2.fill_(float(10 * (rank + 1)))
+        rec.run()
+        ok = ok and torch.equal(got2, full * 2.0)
+        ok = ok and torch.equal(sums2, torch.full((1, 32, 2), float(10 * sum(range(1, world + 1)))))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -62,6 +62,14 @@ def _worker(rank, world, port, frames, guidance_on, q):
         out = runner.denoise((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2, 1.0,
                              gmax)
         res = {"rank": rank, "out": out.float().cpu()}
+        # the recorded-launch replay (default) and the eager module walk must enqueue the very same work
+        runner.use_replay = False
+        eager = runner.denoise((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 3,
+                               1.0, gmax)
+        runner.use_replay = True
+        again = runner.denoise((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 3,
+                               1.0, gmax)
+        res["replay_exact"] = bool(torch.equal(eager, again))
         if rank == 0:
             ref = pipe.denoise((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2,
                                1.0, gmax)
@@ -89,6 +97,7 @@ def test_sharded_loop_equals_single_process(world, frames, guidance_on):
         rel = ((r["out"] - ref).norm() / ref.norm()).item()
         tol = 8e-3   # also for pure CFG-parallel: M halves per rank, so GEMM tile variants / summation order can differ
         assert rel <= tol, f"rank {r['rank']}: sharded vs single-process relative L2 {rel:.3e} (tol {tol})"
+        assert r["replay_exact"], f"rank {r['rank']}: replayed launch list differs from the eager forward"
 
 
 def test_sharded_kernel_variants_are_exact():

@@ -175,3 +175,31 @@ def test_controlnet_encoder_vs_reference_golden(golden_dir):
     dz, mz = z(dev("in_sample").half(), dev("in_t"), dev("in_enc").half(), dev("in_ids"),
                controlnet_cond=dev("in_cond").half(), return_dict=False)
     assert all(float(d.abs().max()) == 0.0 for d in dz) and float(mz.abs().max()) == 0.0
+
+
+def test_recorded_forward_replays_exactly(wiring):
+    """lkgd_amd/replay.py: the recorded launch list, replayed on new inputs written into the same buffers, must produce
+    what the eager module walk produces for those inputs (bit for bit: same kernels, same arguments)"""
+    from lkgd_amd import ops, replay
+    g = wiring
+    _, m = _pair(True, WSEED)
+    B, F, C, H, W = g["in_sample"].shape
+    x = g["in_sample"].to(DEV).half().reshape(B * F, C, H, W).contiguous()
+    tok = ops.nchw_to_tokens(x)
+    t_dev = torch.full((B,), 0.5, dtype=torch.float32, device=DEV)
+    enc = g["in_enc"].to(DEV).half().contiguous()
+    ids = g["in_ids"].to(DEV).float().contiguous()
+    with replay.record() as plan:
+        plan.result, _ = m.forward_tokens(tok, B, F, H, W, t_dev, enc, ids)
+    first = plan.result.clone()
+    eager, _ = m.forward_tokens(tok, B, F, H, W, t_dev, enc, ids)
+    assert torch.equal(first, eager)
+    assert len(plan.calls) > 100 and ops.PLAN is None
+    # new inputs, same addresses
+    tok.copy_(ops.nchw_to_tokens((0.5 * x).contiguous()))
+    t_dev.fill_(3.25)
+    again = plan.run()
+    assert again.data_ptr() == plan.result.data_ptr()
+    eager, _ = m.forward_tokens(tok, B, F, H, W, t_dev, enc, ids)
+    assert torch.equal(again, eager)
+    assert not torch.equal(again, first)

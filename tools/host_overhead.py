@@ -27,3 +27,19 @@ for (frames, h, w, tag) in ((2, 8, 8, "2 frames 8x8 (launch-bound)"), (14, 72, 1
     torch.cuda.synchronize()
     t_all = (time.perf_counter() - t0) / n
     print(f"{tag:26s}: host enqueue {t_host*1e3:7.1f} ms / forward, end-to-end {t_all*1e3:7.1f} ms / forward")
+    # the same forward replayed from a recorded launch list (lkgd_amd/replay.py)
+    from lkgd_amd import replay
+    t_dev = torch.ones(cfgb, dtype=torch.float32, device=dev)
+    with replay.record() as plan:
+        plan.result, _ = unet.forward_tokens(tok, cfgb, frames, h, w, t_dev, emb.half().contiguous(), ids.float().contiguous())
+    plan.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        plan.run()
+    t_host = (time.perf_counter() - t0) / n
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / n
+    print(f"{'':26s}  replayed    {t_host*1e3:7.1f} ms / forward, end-to-end {t_all*1e3:7.1f} ms / forward "
+          f"({len(plan.calls)} launches)")
+    del plan
