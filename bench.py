@@ -128,14 +128,18 @@ def main():
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
-    distributed = world > 1
+    # LKGD_FORCE_DIST=1: take the sharded runner + RCCL path even with one rank (functional check on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("LKGD_FORCE_DIST", "0") == "1"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # "nccl" == RCCL on ROCm.  LKGD_DIST_BACKEND=gloo is a functional-test knob for boxes with fewer GPUs than ranks
         backend = os.environ.get("LKGD_DIST_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
 
@@ -177,7 +181,7 @@ def main():
     def barrier():
         if distributed:
             import torch.distributed as dist
-            dist.barrier()
+            dist.barrier(device_ids=[dev.index]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

@@ -24,6 +24,28 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// exact-erf GELU of two values at once, erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below fp16 resolution).
+// The GEGLU epilogue of a K=320 projection spends more VALU cycles here than the K-loop spends in the matrix pipe, so
+// the form is chosen for instruction count:  gelu(x) = max(x,0) - |x| * (0.5 * poly(t) * t * exp(-x^2/2)),
+// t = 1/(1 + p|x|/sqrt2)  (no sign select, no 1 +- erf), everything but rcp/exp2 on float2 (v_pk_fma_f32 / v_pk_mul_f32).
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2_t gelu_erf2(float2_t x) {
+  const float2_t ax = __builtin_elementwise_abs(x);
+  const float2_t d = __builtin_elementwise_fma(ax, (float2_t)(0.3275911f * 0.70710678118654752440f), (float2_t)(1.0f));
+  const float2_t z = ax * 0.84932180028801904272f;          // z^2 = (x^2 / 2) * log2(e)
+  const float2_t z2 = z * z;
+  float2_t t, e;
+  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+  e.x = __builtin_amdgcn_exp2f(-z2.x); e.y = __builtin_amdgcn_exp2f(-z2.y);
+  float2_t q = __builtin_elementwise_fma(t, (float2_t)(0.5f * 1.061405429f), (float2_t)(0.5f * -1.453152027f));
+  q = __builtin_elementwise_fma(q, t, (float2_t)(0.5f * 1.421413741f));
+  q = __builtin_elementwise_fma(q, t, (float2_t)(0.5f * -0.284496736f));
+  q = __builtin_elementwise_fma(q, t, (float2_t)(0.5f * 0.254829592f));
+  q = q * t;
+  q = q * e;
+  return __builtin_elementwise_fma(-q, ax, __builtin_elementwise_max(x, (float2_t)(0.0f)));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -324,11 +324,14 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   const bool plain = d->mode == LKGD_A_PLAIN;
   const bool rp_ok = rows16 && plain && d->K <= 320 && d->csplit >= d->K && d->geglu != 80;
   const bool pp_ok = rows16 && d->geglu != 80 && d->mode != LKGD_A_CONV3X3_C8 && d->M < (1 << 24);
-  const bool wide_ok = (d->geglu == 80 || d->geglu == 0) && d->mode != LKGD_A_CONV3X3_C8 && d->M < (1 << 24);
+  // (the GEGLU epilogue of the 256x320 kernel is compiled into its plain-linear instantiation only)
+  const bool wide_ok = (d->geglu == 0 || (d->geglu == 80 && plain)) && d->mode != LKGD_A_CONV3X3_C8 &&
+                       d->M < (1 << 24);
   const bool stream_ok = rows16 && d->geglu != 80;
   const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
   int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide, 5 = rowpanel, 6 = ping-pong
   if (d->geglu == 80) {
+    if (!wide_ok) return LKGD_E_SHAPE;
     pick = 4;                                            // 80-wide GEGLU interleave exists only in the 256x320 kernel
   } else if (v != 0) {
     pick = v;
@@ -340,7 +343,7 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     // the 9x16 level (M = 4032): 256-row tilings leave most CUs idle; 128x128 at two workgroups per CU fills best,
     // except for the wide-N projections (QKV: 16 x 12 tiles of 256x320)
     pick = (wide_ok && plain && d->geglu == 0 && d->N % 320 == 0 && d->N >= 2560 && d->M > 256 && !d->res1) ? 4 : 1;
-  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->K >= 320 && tiles_wide * 2 >= cus) {
+  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->K >= 320 && tiles_wide * 2 >= cus - 16) {
     pick = 4;                                            // every N = 320 / 640 / 960 / 1280 / 1920 / 3840 shape of the model
   } else {
     pick = 3;

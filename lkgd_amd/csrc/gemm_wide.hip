@@ -13,24 +13,28 @@
 //   * GEGLU: packed rows interleave 80 hidden | 80 gate per wave (5 + 5 fragments): both factors in the same lane/register.
 #include "gemm_common.h"
 
+// timing-experiment knobs (tools/micro/wide_knobs.sh; results are wrong with NOSTORE): never defined in the product build
+#ifdef WIDE_X_NOSTORE
+#define WIDE_STORE_GUARD if (p.ldc < 0)
+#else
+#define WIDE_STORE_GUARD
+#endif
+#ifdef WIDE_X_SMALLOUT          /* every store lands in the first 2048 rows: the output stays L2-resident */
+#define WIDE_OUT_ROW(m) ((m) & 2047)
+#else
+#define WIDE_OUT_ROW(m) (m)
+#endif
+#ifdef WIDE_X_NT
+#define WIDE_ST(ptr, v) __builtin_nontemporal_store(v, ptr)
+#else
+#define WIDE_ST(ptr, v) (*(ptr) = (v))
+#endif
 #define WBM 256
 #define WBN 320
 #define WNT 512
 #define WSTAGE_BYTES ((WBM + WBN) * BK * 2)   // 72 KiB
-#define WLDS (2 * WSTAGE_BYTES)               // 144 KiB
-
-__device__ __forceinline__ float gelu_fast_w(float x) {
-  // exact-erf GELU, erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-  return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
-}
+#define WBIAS_OFF (2 * WSTAGE_BYTES)          // two 320-float bias strips (tile parity) behind the stages
+#define WLDS (WBIAS_OFF + 2 * WBN * 4)        // 146.5 KiB
 
 // ---- K-tile body (generated asm, tools/gen_wide_asm.py).  hipcc's allocator spills a few values of the C++ form of this
 // loop and reloads them next to the LDS-DMA issue; every scratch reload is followed by s_waitcnt vmcnt(0), which in the
@@ -114,6 +118,9 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
   const int nk = p.K / BK;
   const int total = (my_tiles > 0 ? my_tiles : 0) * nk;
   if (total <= 0) return;
+#ifdef WIDE_X_STAGGER
+  for (int i = 0; i < (c & 3) * WIDE_X_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);   // 127 * 64 clocks each
+#endif
 
   // ---- staging state: describes the K-tile whose loads are issued next
   const int srow = t >> 3;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
   LeanGather<4> ag;           // 2-register row descriptors, division-free segment updates (gemm_common.h)
   float rcp0, rcp1;
   lean_rcps<MODE>(p, rcp0, rcp1);
-  int st_tile = tile_begin - nc, st_kt = nk - 1, st_s = -1;
+  int st_tile = tile_begin - nc, st_kt = nk - 1, st_s = -1, st_par = 0, ep_par = 0;
   ag.seg_k0 = 0; ag.seg_end = 0; ag.zmask = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { ag.rd[i].base = -1; ag.rd[i].yx = 0; ag.aptr[i] = (const half_t*)p.zeros; }
@@ -149,6 +156,14 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
           in.oB[i] = ((unsigned)n * (unsigned)p.K + schunk * 8) * 2u;
         }
         ag.seg_end = 0;
+        // the tile's bias strip rides the LDS-DMA stream too (4 bytes per lane, waves 0-4): the epilogue then reads it with
+        // ds_read_b128 instead of waiting one global-load latency per token fragment
+        st_par ^= 1;
+        if (p.bias && w < 5) {
+          int n = tn * WBN + w * 64 + lane;
+          n = n < p.N ? n : p.N - 1;
+          __builtin_amdgcn_global_load_lds(GLB_PTR(p.bias + n), LDS_PTR(smem + WBIAS_OFF + st_par * (WBN * 4) + w * 256), 4, 0, 0);
+        }
       }
       if (st_kt * BK >= ag.seg_end) {
         lean_segment<MODE, 4>(p, ag, st_kt * BK, schunk);       // aptr = the rows' sources at the segment's first K-tile
@@ -221,10 +236,12 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
       const half_t* r2p = (const half_t*)p.res2;
       half_t* outp = (half_t*)p.out;
       // one token fragment (16 tokens x 160 channels) at a time
+      ep_par ^= 1;
+      const float* bl = (const float*)(smem + WBIAS_OFF + ep_par * (WBN * 4)) + wc * 160 + 4 * lq;   // bias[n0 + ...]
       auto epi = [&](int j, const float4_t (&e)[10]) {
         const long long m = m0 + j * 16;
         if (m >= p.M) return;
-        if (!p.geglu) {
+        if (MODE != LKGD_A_PLAIN || !p.geglu) {
           long long idx = 0;
           if (rbp) idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
 #pragma unroll
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
             const int n = n0 + i * 16;
             if (n < p.N) {
               float4_t v = e[i];
-              if (p.bias) v += *(const float4_t*)(p.bias + n);
+              if (p.bias) v += *(const float4_t*)(bl + i * 16);
               if (rbp) {
                 half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + n);
 #pragma unroll
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
               half4_t o;
 #pragma unroll
               for (int x = 0; x < 4; ++x) o[x] = (half_t)v[x];
-              *(half4_t*)(outp + m * p.ldc + n) = o;
+              WIDE_STORE_GUARD WIDE_ST((half4_t*)(outp + WIDE_OUT_ROW(m) * p.ldc + n), o);
             }
           }
         } else {
@@ -262,13 +279,13 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
           for (int i = 0; i < 5; ++i) {
             float4_t hv = e[i], gv = e[i + 5];
             if (p.bias) {
-              hv += *(const float4_t*)(p.bias + n0 + i * 16);
-              gv += *(const float4_t*)(p.bias + n0 + 80 + i * 16);
+              hv += *(const float4_t*)(bl + i * 16);
+              gv += *(const float4_t*)(bl + 80 + i * 16);
             }
-            half4_t o;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) o[x] = (half_t)(hv[x] * gelu_fast_w(gv[x]));
-            *(half4_t*)(outp + m * p.ldc + oc0 + i * 16) = o;
+            const float2_t lo = __builtin_shufflevector(hv, hv, 0, 1) * gelu_erf2(__builtin_shufflevector(gv, gv, 0, 1));
+            const float2_t hi = __builtin_shufflevector(hv, hv, 2, 3) * gelu_erf2(__builtin_shufflevector(gv, gv, 2, 3));
+            const half4_t o = {(half_t)lo.x, (half_t)lo.y, (half_t)hi.x, (half_t)hi.y};
+            WIDE_STORE_GUARD WIDE_ST((half4_t*)(outp + WIDE_OUT_ROW(m) * p.ldc + oc0 + i * 16), o);
           }
         }
       };

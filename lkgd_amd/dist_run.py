@@ -95,6 +95,7 @@ class DistDenoiser:
             b_local, ids_local = 1, ids[plan.cfg_index:plan.cfg_index + 1]
         else:
             b_local, ids_local = cfg, ids
+        self.shard.B_total = 2 if plan.cfg_groups == 2 else cfg     # batch entries of the whole job (CFG halves)
         if b_local != 1 and plan.frame_shards > 1:
             raise LkgdHipError("frame sharding without CFG-parallel needs guidance off (one batch entry per rank)")
         send = torch.zeros(fmax * HW * b_local, 4, dtype=torch.float16, device=dev)

@@ -44,9 +44,9 @@ def geglu_perm(inner: int, half: int = 32, device=None) -> torch.Tensor:
 
 def geglu_half(n_packed_rows: int, k: int = 0) -> int:
     """interleave width the kernels want for a GEGLU projection with 2*inner = n_packed_rows rows and K = k inputs"""
-    # K <= 320 (the 320-channel level): the register-resident row-panel kernel, 32 hidden | 32 gate per wave.
-    # Otherwise the 256x320 kernel, 80 | 80 per wave, when the rows tile by 320 (measured: profiles/r01_gemm_shapes_ab*.txt)
-    if k > 320 and n_packed_rows % 320 == 0:
+    # the 256x320 kernel, 80 hidden | 80 gate per wave, when the rows tile by 320 (measured: profiles/r01_gemm_shapes_ab*.txt;
+    # since its bias strip comes through LDS it also leads at K = 320); otherwise 32 | 32 for the other kernels
+    if k >= 320 and n_packed_rows % 320 == 0:
         return 80
     return 32
 
