@@ -47,6 +47,21 @@
 #else
 #define WIDE_LD(X) X
 #endif
+#ifdef WIDE_X_NOREAD
+#define WIDE_RD(X) ""
+#else
+#define WIDE_RD(X) X
+#endif
+#ifdef WIDE_X_NOMFMA
+#define WIDE_MM(X) ""
+#else
+#define WIDE_MM(X) X
+#endif
+#ifdef WIDE_X_NOBAR
+#define WIDE_BAR(X) ""
+#else
+#define WIDE_BAR(X) X
+#endif
 #include "gemm_wide_ktile.inc"
 
 struct WideIn {                 // what one K-tile body needs about the NEXT K-tile (its nine DMA loads), besides the
@@ -242,8 +257,9 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
         const long long m = m0 + j * 16;
         if (m >= p.M) return;
         if (MODE != LKGD_A_PLAIN || !p.geglu) {
-          long long idx = 0;
-          if (rbp) idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
+          unsigned idx = 0;          // 32-bit row-map arithmetic: M < 2^24 is a launch condition of this kernel
+          if (rbp) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) +
+                          (unsigned)p.rb_c0) % (unsigned)p.rb_md;
 #pragma unroll
           for (int i = 0; i < 10; ++i) {
             const int n = n0 + i * 16;
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
               float4_t v = e[i];
               if (p.bias) v += *(const float4_t*)(bl + i * 16);
               if (rbp) {
-                half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + n);
+                half4_t rb = *(const half4_t*)(rbp + (long long)idx * p.ldrb + n);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) v[x] += (float)rb[x];
               }

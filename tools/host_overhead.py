@@ -12,7 +12,10 @@ from lkgd_amd import ops
 
 dev = torch.device("cuda", 0)
 unet = B.build_unet(dev, False)
-for (frames, h, w, tag) in ((2, 8, 8, "2 frames 8x8 (launch-bound)"), (14, 72, 128, "C2 full"), (4, 72, 128, "4 frames (8-GPU slice)")):
+ONLY = os.environ.get("LKGD_CASE")          # "0" / "1" / "2": run one case only (for rocprofv3 --stats of that case)
+for ci, (frames, h, w, tag) in enumerate(((2, 8, 8, "2 frames 8x8 (launch-bound)"), (14, 72, 128, "C2 full"), (4, 72, 128, "4 frames (8-GPU slice)"))):
+    if ONLY is not None and int(ONLY) != ci:
+        continue
     lat0, img, emb, ids = B.synthetic_inputs(dev, frames, h, w)
     cfgb = 2
     tok = ops.prepare_unet_input(lat0.half(), img, 2, 700.0)

@@ -26,7 +26,8 @@ while time.time() - t0 < 2.0:
 M0 = 28 * 72 * 128
 for (name, M, N, K, geglu, res) in (("L0 geglu", M0, 2560, 320, True, False), ("L0 ffout", M0, 320, 1280, False, True),
                                     ("L0 qkv", M0, 960, 320, False, False), ("L1 geglu", M0 // 4, 5120, 640, True, False),
-                                    ("L2 ffout", M0 // 16, 1280, 5120, False, True)):
+                                    ("L2 ffout", M0 // 16, 1280, 5120, False, True),
+                                    ("deep K", 32768, 2560, 5120, False, False)):
     a = torch.randn(M, K, device=DEV, dtype=torch.float16) * 0.1
     w = torch.randn(N, K, device=DEV, dtype=torch.float16) * 0.1
     # (GEGLU weights would be row-permuted by lkgd_amd.packing; irrelevant for the time)
