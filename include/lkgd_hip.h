@@ -87,6 +87,11 @@ typedef struct lkgd_gemm_desc {
   int32_t ldr1, ldr2, ldc;
   float s_acc, r1, r2;
   int32_t geglu;           /* 0 = off, 32 or 80 = GEGLU interleave width (see above) */
+  void* workspace;         /* optional fp32 scratch for split-K partial sums (NULL = never split).  Few-row problems */
+  int64_t workspace_bytes; /* (M < 8192: the 18x32 / 9x16 levels, or a frame-sharded rank's slice) fill a fraction of
+                              the CUs with 128x128 tiles; K is then cut into up to 16 slices whose fp32 partial tiles
+                              go to [slice][M][N] here and a second kernel adds them in slice order and runs the
+                              epilogue - deterministic, no atomics.  One GEMM at a time may use a workspace. */
 } lkgd_gemm_desc;
 
 int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream);

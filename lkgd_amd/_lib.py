@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("ldc", C.c_int32),
         ("s_acc", C.c_float), ("r1", C.c_float), ("r2", C.c_float),
         ("geglu", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -20,7 +20,9 @@
 #define STAGE_BYTES (2 * BM * BK * 2)  // A 16 KiB + B 16 KiB
 #define GEMM_LDS (2 * STAGE_BYTES)     // 64 KiB (also holds the fp32 C tile in the epilogue)
 
-__global__ __launch_bounds__(256, 2) void lkgd_gemm_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n) {
+// ksplit > 1: blockIdx.y owns K-tiles [y*per, (y+1)*per) and leaves its fp32 partial tile in ws[y][M][N]
+__global__ __launch_bounds__(256, 2) void lkgd_gemm_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit,
+                                                           int per, float* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -43,7 +45,10 @@ __global__ __launch_bounds__(256, 2) void lkgd_gemm_kernel(const lkgd_gemm_desc 
     int n = n0 + srow + 32 * i;
     brow[i] = n < p.N ? (const half_t*)p.w + (long long)n * p.K + schunk * 8 : nullptr;
   }
-  a_segment<4>(p, ag, 0, schunk);
+  const int nk_all = p.K / BK;
+  const int kb = ksplit > 1 ? (int)blockIdx.y * per : 0;
+  const int ke = ksplit > 1 ? (kb + per < nk_all ? kb + per : nk_all) : nk_all;
+  a_segment<4>(p, ag, kb * BK, schunk);
 
   auto stage = [&](int buf, int kt) {
     char* sa = smem + buf * STAGE_BYTES;
@@ -76,13 +81,12 @@ __global__ __launch_bounds__(256, 2) void lkgd_gemm_kernel(const lkgd_gemm_desc 
     b_off[i] = BM * BK * 2 + rb * 128; b_sw[i] = (rb >> 1) & 7;
   }
 
-  const int nk = p.K / BK;
-  stage(0, 0);
+  stage(0, kb);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+  for (int kt = kb; kt < ke; ++kt) {
+    const int cur = (kt - kb) & 1;
+    if (kt + 1 < ke) stage(cur ^ 1, kt + 1);
     const char* sbase = smem + cur * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -116,7 +120,39 @@ __global__ __launch_bounds__(256, 2) void lkgd_gemm_kernel(const lkgd_gemm_desc 
       }
   __syncthreads();
 
+  if (ksplit > 1) {
+    // partial tile -> workspace, 16-byte row-contiguous stores; the epilogue runs in lkgd_gemm_splitk_reduce
+    float* dst = ws + (long long)blockIdx.y * p.M * p.N;
+    const int col = (t & 31) * 4;
+    if (n0 + col < p.N) {
+      for (int row = t >> 5; row < BM && m0 + row < p.M; row += 8)
+        *(float4_t*)(dst + (long long)(m0 + row) * p.N + n0 + col) = *(const float4_t*)(ct + row * BN + col);
+    }
+    return;
+  }
   gemm_epilogue<BM, BN, 256>(p, ct, t, m0, n0, tn);
+}
+
+// second pass of a split-K GEMM: 32 x 128 output tile per workgroup, partials added in slice order, then the shared epilogue
+__global__ __launch_bounds__(256) void lkgd_gemm_splitk_reduce(const lkgd_gemm_desc p, int tiles_n, int ksplit,
+                                                               const float* ws) {
+  __shared__ __attribute__((aligned(16))) float ct[32 * BN];
+  const int t = threadIdx.x;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * 32, n0 = tn * BN;
+  const int col = (t & 31) * 4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (t >> 5) + 8 * it;
+    float4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (m0 + row < p.M && n0 + col < p.N) {
+      const float* src = ws + (long long)(m0 + row) * p.N + n0 + col;
+      for (int s = 0; s < ksplit; ++s) v += *(const float4_t*)(src + (long long)s * p.M * p.N);
+    }
+    *(float4_t*)(ct + row * BN + col) = v;
+  }
+  __syncthreads();
+  gemm_epilogue<32, BN, 256>(p, ct, t, m0, n0, tn);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -291,6 +327,8 @@ extern "C" int lkgd_gemm_pp_launch(const lkgd_gemm_desc* d, hipStream_t stream, 
 // 6 = force the 256x256 ping-pong kernel where it applies
 static int gemm_variant_override = 0;
 extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = v; }
+static bool gemm_splitk_enabled = true;
+extern "C" void lkgd_debug_set_gemm_splitk(int on) { gemm_splitk_enabled = on != 0; }
 
 extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   int rc = check_desc(d);
@@ -373,8 +411,32 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     int tiles_m = (d->M + BM - 1) / BM;
     long long nwg = (long long)tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) return LKGD_E_SHAPE;
-    hipLaunchKernelGGL(lkgd_gemm_kernel, dim3((unsigned)nwg), dim3(256), GEMM_LDS, (hipStream_t)stream, *d, tiles_m,
-                       tiles_n);
+    // split-K when the tiles fill less than half of the 2-per-CU workgroup slots: slices of >= 4 K-tiles, as many as
+    // the slots and the caller's workspace take (include/lkgd_hip.h: lkgd_gemm_desc.workspace)
+    int ksplit = 1, per = d->K / BK;
+    const int nk = d->K / BK;
+    const long long slots = 2LL * cus;
+    if (gemm_splitk_enabled && d->workspace && aligned16(d->workspace) && d->N % 4 == 0 && nwg * 2 <= slots && nk >= 8) {
+      long long want = slots / nwg;
+      if (want > nk / 4) want = nk / 4;
+      if (want > 16) want = 16;
+      const long long fit = d->workspace_bytes / ((long long)d->M * d->N * 4);
+      if (want > fit) want = fit;
+      if (want >= 2) {
+        per = (int)((nk + want - 1) / want);
+        ksplit = (nk + per - 1) / per;           // every slice non-empty
+      }
+    }
+    if (ksplit > 1) {
+      hipLaunchKernelGGL(lkgd_gemm_kernel, dim3((unsigned)nwg, (unsigned)ksplit), dim3(256), GEMM_LDS,
+                         (hipStream_t)stream, *d, tiles_m, tiles_n, ksplit, per, (float*)d->workspace);
+      const unsigned rblocks = (unsigned)(((d->M + 31) / 32) * tiles_n);
+      hipLaunchKernelGGL(lkgd_gemm_splitk_reduce, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *d, tiles_n, ksplit,
+                         (const float*)d->workspace);
+    } else {
+      hipLaunchKernelGGL(lkgd_gemm_kernel, dim3((unsigned)nwg), dim3(256), GEMM_LDS, (hipStream_t)stream, *d, tiles_m,
+                         tiles_n, 1, nk, (float*)nullptr);
+    }
   }
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }

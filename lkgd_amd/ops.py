@@ -50,6 +50,20 @@ def zeros_page(device) -> torch.Tensor:
     return z
 
 
+_splitk_ws = {}
+SPLITK_WORKSPACE_BYTES = 64 << 20
+
+
+def splitk_workspace(device) -> torch.Tensor:
+    """fp32 scratch for the split-K partial sums of few-row GEMMs; one per device: GEMMs are stream-ordered"""
+    key = (device.type, device.index)
+    w = _splitk_ws.get(key)
+    if w is None:
+        w = torch.empty(SPLITK_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        _splitk_ws[key] = w
+    return w
+
+
 def _req(t: torch.Tensor, dtype, name: str):
     if not t.is_cuda:
         raise _lib.LkgdHipError(f"{name}: expected a GPU tensor (lkgd_amd has no CPU path)")
@@ -121,6 +135,9 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     d.ldc = _ld(out)
     d.s_acc, d.r1, d.r2 = s_acc, r1, r2
     d.geglu = int(geglu)        # 0 off, 32 / 80 = interleave width the weights were packed with
+    if M < 8192:                # few-row problems may cut K into slices (lkgd_hip.h: lkgd_gemm_desc.workspace)
+        ws = splitk_workspace(out.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     ev = GEMM_EVENTS
     if ev is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

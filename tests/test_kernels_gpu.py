@@ -426,3 +426,51 @@ def test_fsm_rows_rejects_bad_descriptors():
     with pytest.raises(LkgdHipError):
         ops.fsm_rows(a, a, pairs=1, HW=8, C_=64, a_rows=(8, 0), o_rows=(8, 0),
                      csr=(off, off[:4], off[:3], torch.zeros(4, device=DEV)))
+
+
+def test_gemm_split_k_few_rows():
+    """few-row problems (a frame-sharded rank's 9x16 level: 576 rows) cut K into slices with fp32 partial tiles in the
+    caller's workspace and a deterministic second pass; same result as the unsplit kernel up to fp32 summation order"""
+    from lkgd_amd import _lib, ops
+    from lkgd_amd.packing import pack_conv3x3, pack_geglu
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(21)
+    # 3x3 conv, two sources, time-embedding row bias, residual: M = 4 * 12 * 12 = 576, K = 9 * 256
+    N, C0, C1, Cout, H, W = 4, 128, 128, 192, 12, 12
+    x0, x1 = _h(torch.randn(N, C0, H, W, generator=g)), _h(torch.randn(N, C1, H, W, generator=g))
+    w = _h(torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 48)
+    b = torch.randn(Cout, generator=g)
+    temb = _h(torch.randn(N, Cout, generator=g))
+    res = _h(torch.randn(N * H * W, Cout, generator=g))
+    ref = F.conv2d(torch.cat([x0, x1], 1).float(), w.float(), b, padding=1) + temb.float()[:, :, None, None]
+    ref = 0.75 * ref + 0.5 * _untokens(res.float(), N, H, W)
+    outs = []
+    for on in (1, 0):
+        L.lkgd_debug_set_gemm_splitk(on)
+        out = torch.empty(N * H * W, Cout, dtype=torch.float16, device=DEV)
+        ops.gemm(_tokens(x0).to(DEV), pack_conv3x3(w).to(DEV), out, M=N * H * W, N=Cout, K=9 * (C0 + C1),
+                 a1=_tokens(x1).to(DEV), csplit=C0, bias=b.to(DEV), mode=ops.A_CONV3X3, Cin=C0 + C1,
+                 conv=(H, W, H, W, 1, 0), rowbias=temb.to(DEV), rowmap=ops.rowmap_div(H * W), res1=res.to(DEV),
+                 s_acc=0.75, r1=0.5)
+        outs.append(out.float().cpu())
+    L.lkgd_debug_set_gemm_splitk(1)
+    _close(_untokens(outs[0], N, H, W), ref, what="split-K conv3x3")
+    assert (outs[0] - outs[1]).abs().max().item() <= 4e-3 * ref.abs().max().item()
+    # run-to-run determinism of the two-pass reduction
+    out2 = torch.empty(N * H * W, Cout, dtype=torch.float16, device=DEV)
+    ops.gemm(_tokens(x0).to(DEV), pack_conv3x3(w).to(DEV), out2, M=N * H * W, N=Cout, K=9 * (C0 + C1),
+             a1=_tokens(x1).to(DEV), csplit=C0, bias=b.to(DEV), mode=ops.A_CONV3X3, Cin=C0 + C1,
+             conv=(H, W, H, W, 1, 0), rowbias=temb.to(DEV), rowmap=ops.rowmap_div(H * W), res1=res.to(DEV),
+             s_acc=0.75, r1=0.5)
+    assert torch.equal(out2.float().cpu(), outs[0])
+    # GEGLU (32 | 32 interleave) with ragged rows: M = 301, K = 1280
+    M, C = 301, 1280
+    a = _h(torch.randn(M, C, generator=g))
+    wg = torch.randn(512, C, generator=g) / C ** 0.5
+    bg = torch.randn(512, generator=g) * 0.1
+    y = a.float() @ _h(wg).float().T + bg
+    hid, gate = y.chunk(2, dim=-1)
+    wp, bp, half = pack_geglu(wg, bg, half=32)
+    out = torch.empty(M, 256, dtype=torch.float16, device=DEV)
+    ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=512, K=C, bias=bp.to(DEV), geglu=half)
+    _close(out, hid * F.gelu(gate), what="split-K geglu")
