@@ -8,8 +8,13 @@ BASELINE.json's north_star names and SURVEY.md 8e details:
 * inside a CFG half the F frames are split into contiguous slices (14 frames over 4 shards = 4,4,3,3).  All spatial work
   (2-D convs, spatial attention, feed-forwards, per-frame GroupNorm) is local.  Temporal ops couple frames at a pixel:
   - temporal GroupNorm: all-reduce of the [32,2] fp32 partial sums (not the activations),
-  - temporal Conv3d (3,1,1) and temporal attention K/V: all-gather of the frame slices (padded to equal size, because
-    RCCL's all-gather wants equal counts) right before the op.
+  - temporal Conv3d (3,1,1): needs one frame of halo on each side only - an equal-count all-gather of every rank's two
+    BOUNDARY frames (2 of its 3-7 frames; no padding needed) fills the halo slots of a [f_local + 2] frame buffer,
+  - temporal attention: all-gather of the normalised hidden states of the frame slices (C channels, padded to equal
+    size because RCCL's all-gather wants equal counts); K|V for all frames are then projected locally (a 2C x C GEMM
+    on F*HW rows is microseconds; gathering K|V themselves would move twice the bytes).
+  Per forward a rank of 8 receives 1.2 GB this way (2.2 GB with whole-slice gathers before every temporal op), a rank
+  of 4 0.6 GB (1.5 GB) - SURVEY.md 8e lists the message sizes.
 
 This module is the HOST logic of that scheme: the shard plan and the padded gather.  It is pure torch.distributed
 (backend "nccl" == RCCL on the GPU box, "gloo" in the CPU tests), no kernels.
@@ -126,6 +131,31 @@ def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Ten
             dst.copy_(src)
     _step(compact)
     return out
+
+
+def exchange_halo(buf: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+    """buf [f_local + 2, ...] with the rank's own frames already in slots 1..f_local: fills slot 0 with the previous
+    shard's last frame and slot f_local + 1 with the next shard's first one.  At the ends of the clip the slot is left as
+    the caller allocated it (zeros = the Conv3d's zero padding).  One all-gather of two boundary frames per rank."""
+    k, fl, si = plan.frame_shards, plan.f_local, plan.shard_index
+    if k == 1:
+        return buf
+    if buf.shape[0] != fl + 2 or not buf.is_contiguous():
+        raise ValueError("halo buffer must be a contiguous [f_local + 2, ...] tensor")
+    frame = tuple(buf.shape[1:])
+    send = torch.empty((2,) + frame, dtype=buf.dtype, device=buf.device)
+    got = torch.empty((2 * k,) + frame, dtype=buf.dtype, device=buf.device)
+
+    def step():
+        send[0].copy_(buf[1])
+        send[1].copy_(buf[fl])
+        all_gather_into(got, send, group)
+        if si > 0:
+            buf[0].copy_(got[2 * (si - 1) + 1])
+        if si < k - 1:
+            buf[fl + 1].copy_(got[2 * (si + 1)])
+    _step(step)
+    return buf
 
 
 def allreduce_sums(sums: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:

@@ -1,9 +1,9 @@
 """Multi-GPU execution of ONE clip's denoising loop: CFG-parallel x frame slices, one process per GPU, RCCL.
 
 Exchange points per UNet forward on a rank (frame_shards > 1 only):
-  * each temporal GroupNorm  : all-reduce of [1,32,2] fp32 sums                       (22 blocks x 2)
-  * each temporal Conv3d     : all-gather of the normalised frame slices [F,HW,C]     (22 blocks x 2)
-  * each temporal attention  : all-gather of K|V [F,HW,2C]                            (16 blocks)
+  * each temporal GroupNorm  : all-reduce of [1,32,2] fp32 sums                            (22 blocks x 2)
+  * each temporal Conv3d     : all-gather of every rank's two boundary frames [2,HW,C]     (22 blocks x 2)
+  * each temporal attention  : all-gather of the normalised hidden states [F,HW,C]; K|V projected locally (16 blocks)
 and once per step, over ALL ranks, the all-gather of the noise prediction [cfg*F*HW, 4] (1 MB) before the replicated
 CFG-combine + Euler update.  With 2 GPUs (pure CFG-parallel) only the last exchange exists.
 
@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from . import ops, replay
 from ._lib import LkgdHipError
-from .dist import ShardPlan, all_gather_into, allreduce_sums, gather_frames, make_plan
+from .dist import ShardPlan, all_gather_into, allreduce_sums, exchange_halo, gather_frames, make_plan
 
 
 class ShardInfo:
@@ -46,6 +46,12 @@ class ShardInfo:
 
     def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
         return allreduce_sums(sums, self.plan, self.group)
+
+    def halo(self, buf: torch.Tensor) -> torch.Tensor:
+        """[(f_local+2)*HW, C] tokens with the own frames in the middle -> neighbours' boundary frames in the two end slots"""
+        fl = self.plan.f_local
+        exchange_halo(buf.reshape(fl + 2, -1, buf.shape[-1]), self.plan, self.group)
+        return buf
 
 
 class DistDenoiser:

@@ -417,11 +417,14 @@ class TemporalBasicTransformerBlock(nn.Module):
             ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
                               self.attn1.heads)
         else:
-            # frames of the clip live on several GPUs: local queries against the all-gathered keys / values
-            q, kv = ctx.new(T, Cc), ctx.new(T, 2 * Cc)
+            # frames of the clip live on several GPUs: local queries against the keys / values of ALL frames.  The
+            # normalised hidden states are gathered (C channels) and K|V projected here for every frame: half the
+            # bytes of gathering K|V, for a 2C x C GEMM on F*HW rows
+            ln1f = ctx.shard.gather(ln1)
+            Tf = ln1f.shape[0]
+            q, kvf = ctx.new(T, Cc), ctx.new(Tf, 2 * Cc)
             ops.gemm(ln1, pk.a1.wqkv[:Cc], q, M=T, N=Cc, K=Cc, bias=pk.a1.bqkv[:Cc])
-            ops.gemm(ln1, pk.a1.wqkv[Cc:], kv, M=T, N=2 * Cc, K=Cc, bias=pk.a1.bqkv[Cc:])
-            kvf = ctx.shard.gather(kv)
+            ops.gemm(ln1f, pk.a1.wqkv[Cc:], kvf, M=Tf, N=2 * Cc, K=Cc, bias=pk.a1.bqkv[Cc:])
             ops.attn_temporal(q, kvf[:, :Cc], kvf[:, Cc:], att, ctx.B, ctx.F_total, ctx.HW, self.attn1.heads,
                               Fq=ctx.F)
         xtab = ctx.xb_all[:, pk.xoff:pk.xoff + Cc]
@@ -596,7 +599,8 @@ class SpatioTemporalResBlock(nn.Module):
         ops.gemm(n2, pk.w2, s, M=T, N=Cout, K=9 * Cout, bias=pk.b2, mode=ops.A_CONV3X3, Cin=Cout, conv=geo, res1=sc)
         # --- TemporalResnetBlock on [B, C, F, H, W] == the same tokens; GroupNorm statistics span all F frames
         n3 = self._temporal_norm(ctx, s, pk.tn1, pk.teps)
-        tgeo = (ctx.F_total, ctx.HW, ctx.F, ctx.f0)
+        # sharded: n3 / n4 are [F + 2] frame buffers (own frames + one halo frame per side), output frames start at slot 1
+        tgeo = (ctx.F + 2, ctx.HW, ctx.F, 1) if ctx.frames_sharded else (ctx.F, ctx.HW, ctx.F, 0)
         h = ctx.new(T, Cout)
         ops.gemm(n3, pk.tw1, h, M=T, N=Cout, K=3 * Cout, bias=pk.tb1, mode=ops.A_TCONV3, Cin=Cout,
                  tconv=tgeo, rowbias=ctx.temb_all[:, pk.toff_t:pk.toff_t + Cout], rowmap=bmap)
@@ -609,15 +613,16 @@ class SpatioTemporalResBlock(nn.Module):
 
     @staticmethod
     def _temporal_norm(ctx: Ctx, x: torch.Tensor, affine, eps: float) -> torch.Tensor:
-        """GroupNorm over (C/32, F, H, W) + SiLU, returned for ALL frames (the Conv3d that follows needs the +-1 frame
-        halo).  Sharded: all-reduce the [32,2] partial sums, normalise the local frames, all-gather them."""
+        """GroupNorm over (C/32, F, H, W) + SiLU.  Sharded: all-reduce the [32,2] partial sums, normalise the local frames
+        into the middle of an [F + 2]-frame buffer and fetch the neighbours' boundary frames into its two end slots (the
+        Conv3d (3,1,1) that follows needs +-1 frame; at the clip's ends the slot stays zero = the conv's padding)."""
         if not ctx.frames_sharded:
             return ops.groupnorm_silu(x, None, ctx.B, ctx.F * ctx.HW, *affine, eps)
         sums = ctx.shard.allreduce(ops.groupnorm_sums(x, None, ctx.B, ctx.F * ctx.HW))
         stats = ops.groupnorm_finalize(sums, float(ctx.F_total) * ctx.HW * (x.shape[1] // 32), eps)
-        local = ctx.new(x.shape[0], x.shape[1])
-        ops.groupnorm_apply(x, None, ctx.B, ctx.F * ctx.HW, stats, *affine, True, local)
-        return ctx.shard.gather(local)
+        buf = torch.zeros((ctx.F + 2) * ctx.HW, x.shape[1], dtype=torch.float16, device=x.device)
+        ops.groupnorm_apply(x, None, ctx.B, ctx.F * ctx.HW, stats, *affine, True, buf[ctx.HW:(ctx.F + 1) * ctx.HW])
+        return ctx.shard.halo(buf)
 
 
 class Downsample2D(nn.Module):

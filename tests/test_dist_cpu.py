@@ -58,6 +58,13 @@ def _worker(rank, world, port, frames, q):
         # fp16 payload, as the activations are
         h = gather_frames(local.half(), plan)
         ok = ok and torch.equal(h, full.half())
+        # boundary-frame exchange for the Conv3d halo: slots 0 / f_local+1 <- neighbours' last / first frame, zero at the ends
+        from lkgd_amd.dist import exchange_halo
+        hb = torch.zeros(plan.f_local + 2, 3, 5)
+        hb[1:plan.f_local + 1] = local
+        exchange_halo(hb, plan)
+        padded = torch.cat([torch.zeros(1, 3, 5), full, torch.zeros(1, 3, 5)])
+        ok = ok and torch.equal(hb, padded[plan.f0:plan.f0 + plan.f_local + 2])
         # recorded exchange steps (lkgd_amd/replay.py): new values in the same buffers, same plan
         from lkgd_amd import replay
         src = local.clone()
@@ -89,3 +96,18 @@ def test_uneven_frame_gather_world2(frames):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert res == [(0, True), (1, True)]
+
+
+def test_frame_exchanges_world4():
+    """14 frames over 4 shards (4, 4, 3, 3): interior ranks have a neighbour on both sides of the Conv3d halo"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, 14, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(4))
+    assert res == [(r, True) for r in range(4)]
