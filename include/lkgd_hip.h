@@ -233,6 +233,21 @@ int lkgd_conv3x3_small(const void* in, int32_t Cin, int32_t ldi, const void* w, 
                        int32_t Cout, int32_t ldo, int64_t nimg, int32_t Hin, int32_t Win, int32_t stride,
                        int32_t silu, lkgd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * 11. Clip-level image pre-processing of the CLIP branch (boundary stage, once per clip):
+ *     `_resize_with_antialiasing` of pipeline/pipeline_stable_video_diffusion_trans.py:661-765 =
+ *       separable Gaussian blur with reflect padding (`_gaussian_blur2d` :752-765, `_filter2d` :713-733: one 1-D pass
+ *       along W, one along H; the taps are `_gaussian` :736-749, computed by the caller)
+ *       + `F.interpolate(mode="bicubic", align_corners=True)` (:686).
+ *     fp32 planes [planes][H][W] (planes = batch * channels).  `lkgd_conv1d_reflect`: out[p,y,x] = sum_j taps[j] *
+ *     in[p, reflect(y or x + j - (ntaps-1)/2)], axis 1 = along W, 0 = along H; in != out.
+ *     `lkgd_resize_bicubic_ac`: cubic convolution A = -0.75, source index dst*(in-1)/(out-1), border clamp.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_conv1d_reflect(const float* in, float* out, int64_t planes, int32_t H, int32_t W, const float* taps,
+                        int32_t ntaps, int32_t axis, lkgd_stream_t stream);
+int lkgd_resize_bicubic_ac(const float* in, int64_t planes, int32_t H, int32_t W, float* out, int32_t Ho, int32_t Wo,
+                           lkgd_stream_t stream);
+
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
 

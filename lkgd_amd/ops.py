@@ -382,3 +382,25 @@ def euler_step(model_output: torch.Tensor, sample: torch.Tensor, sigma: float, s
                                      mo.numel(), sigma, sigma_next, 1 if v_prediction else 0, _stream()),
           "lkgd_euler_step")
     return prev
+
+
+def conv1d_reflect(x: torch.Tensor, taps: torch.Tensor, axis: int) -> torch.Tensor:
+    """fp32 [B,C,H,W]: 1-D filter along W (axis 1) or H (axis 0) with reflect padding (lkgd_hip.h section 11)"""
+    _req(x, torch.float32, "x"); _req(taps, torch.float32, "taps")
+    assert x.is_contiguous() and taps.is_contiguous() and x.dim() == 4
+    b, c, h, w = x.shape
+    out = torch.empty_like(x)
+    check(_L().lkgd_conv1d_reflect(x.data_ptr(), out.data_ptr(), b * c, h, w, taps.data_ptr(), taps.numel(), axis,
+                                   _stream()), "lkgd_conv1d_reflect")
+    return out
+
+
+def resize_bicubic_ac(x: torch.Tensor, ho: int, wo: int) -> torch.Tensor:
+    """fp32 [B,C,H,W] -> [B,C,ho,wo], bicubic (A = -0.75), align_corners=True"""
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous() and x.dim() == 4
+    b, c, h, w = x.shape
+    out = torch.empty(b, c, ho, wo, dtype=torch.float32, device=x.device)
+    check(_L().lkgd_resize_bicubic_ac(x.data_ptr(), b * c, h, w, out.data_ptr(), ho, wo, _stream()),
+          "lkgd_resize_bicubic_ac")
+    return out

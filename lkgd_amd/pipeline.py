@@ -21,6 +21,8 @@ import torch
 
 from . import ops
 from ._lib import LkgdHipError
+from .image_ops import resize_with_antialiasing
+from .image_processor import VaeImageProcessor, tensor2vid
 from .scheduler import EulerDiscreteScheduler
 
 
@@ -48,6 +50,7 @@ class StableVideoDiffusionPipeline:
         self.scheduler = scheduler if scheduler is not None else EulerDiscreteScheduler.from_svd_config()
         self.feature_extractor = feature_extractor
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)       # reference :150
         self._guidance_scale = None
         self._num_timesteps = 0
         #: replay the per-step UNet forward from a captured HIP graph (one launch instead of ~1000): the forward is
@@ -114,12 +117,15 @@ class StableVideoDiffusionPipeline:
         return ops.scale(latents, float(self.scheduler.init_noise_sigma))
 
     def _encode_image(self, image, device, num_videos_per_prompt, do_classifier_free_guidance):
-        """boundary stage (CLIP), reference :157-203; tensor input only (the PIL resize path is 8f rank 2)"""
+        """boundary stage (CLIP), reference :157-203; the image encoder itself is the caller's module"""
         if self.image_encoder is None:
             raise LkgdHipError("no image_encoder given: pass `image_embeddings=` to __call__ or call denoise()")
         if not isinstance(image, torch.Tensor):
-            raise NotImplementedError("PIL input needs the CLIP preprocessing boundary stage (SURVEY.md 8f rank 2); "
-                                      "pass a [B,3,224,224] tensor in [0,1] or precomputed image_embeddings")
+            # reference :166-175: PIL -> [0,1] tensor, normalise, anti-aliased resize to CLIP's 224x224, un-normalise
+            image = self.image_processor.numpy_to_pt(self.image_processor.pil_to_numpy(image))
+            image = image * 2.0 - 1.0
+            image = resize_with_antialiasing(image, (224, 224))
+            image = (image + 1.0) / 2.0
         dtype = next(self.image_encoder.parameters()).dtype
         image = self.feature_extractor(images=image, do_normalize=True, do_center_crop=False, do_resize=False,
                                        do_rescale=False, return_tensors="pt").pixel_values
@@ -285,9 +291,7 @@ class StableVideoDiffusionPipeline:
             image_embeddings = self._encode_image(image, device, num_videos_per_prompt, cfg)
         fps = fps - 1
         if image_latents is None:
-            if not isinstance(image, torch.Tensor):
-                raise NotImplementedError("PIL input needs the VaeImageProcessor boundary stage (SURVEY.md 8f rank 2)")
-            img = (2.0 * image - 1.0).to(device)
+            img = self.image_processor.preprocess(image, height=height, width=width).to(device)      # reference :435
             noise = torch.randn(img.shape, generator=generator, device=img.device, dtype=img.dtype)
             img = img + noise_aug_strength * noise
             image_latents = self._encode_vae_image(img, device, num_videos_per_prompt, cfg)
@@ -302,9 +306,10 @@ class StableVideoDiffusionPipeline:
         if controlnet_condition is not None:
             # reference :546-550: VaeImageProcessor.preprocess ([0,1] -> [-1,1]), add the batch axis, duplicate for CFG
             cc = controlnet_condition
-            if not isinstance(cc, torch.Tensor):
-                raise NotImplementedError("PIL conditioning needs the VaeImageProcessor boundary stage (SURVEY.md 8f rank 2)")
-            cc = 2.0 * cc.to(device) - 1.0
+            if isinstance(cc, torch.Tensor) and cc.dim() == 5:      # already batched [1,F,3,H,W] in [0,1]
+                cc = 2.0 * cc.to(device) - 1.0
+            else:
+                cc = self.image_processor.preprocess(cc, height=height, width=width).to(device)
             if cc.dim() == 4:
                 cc = cc.unsqueeze(0)
             controlnet_condition = torch.cat([cc] * 2) if cfg else cc
@@ -314,10 +319,7 @@ class StableVideoDiffusionPipeline:
                            controlnet_cond_scale)
         if output_type != "latent":
             frames = self.decode_latents(lat, num_frames, decode_chunk_size)
-            if output_type == "pt":
-                pass
-            else:
-                raise NotImplementedError("output_type 'pil'/'np' needs the VaeImageProcessor boundary stage")
+            frames = tensor2vid(frames, self.image_processor, output_type=output_type)               # reference :644
         else:
             frames = lat
         if not return_dict:

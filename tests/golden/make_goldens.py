@@ -535,10 +535,35 @@ def gen_loop(pipe_mod, ref_stock, sched_mod):
     print("loop: final std %.4f (3 steps), ids %s" % (out["final"].std(), rec["ids"].tolist()))
 
 
+from image_cases import IMAGE_CASES, image_case_input   # noqa: E402  (shared with tests/test_image_ops*.py)
+
+
+def gen_image_ops(pipe_mod):
+    """`_resize_with_antialiasing` (reference pipeline_stable_video_diffusion_trans.py:661-765) on seeded images; inputs
+    are regenerated from the seed by the tests (image_case_input), the full-size case stores every 4th output pixel"""
+    out = {}
+    for i, (name, shape, size, sub) in enumerate(IMAGE_CASES):
+        y = pipe_mod._resize_with_antialiasing(image_case_input(shape, 900 + i), size)
+        out[name] = y[..., ::sub, ::sub].contiguous()
+        out[name + "_mean"] = y.mean().reshape(1)
+    save_file(out, os.path.join(HERE, "image_ops.safetensors"))
+    print("image_ops:", {k: tuple(v.shape) for k, v in out.items() if not k.endswith("_mean")})
+
+
 def main():
     assert os.path.isdir(REF), "runs only where /root/reference is mounted"
     install_stubs()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "image_ops":       # only this fixture (the others are unchanged)
+        for m in ("models", "utils"):
+            _mod(m)
+        sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
+        ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
+                             "models.unet_spatio_temporal_condition_controlnet")
+        sys.modules["models.unet_spatio_temporal_condition_controlnet"] = ref_stock
+        sys.modules["utils.scheduling_euler_discrete_karras_fix"] = sched_mod
+        gen_image_ops(load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans"))
+        return
     sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
     gen_scheduler(sched_mod)
     ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
@@ -567,6 +592,7 @@ def main():
     sys.modules["utils.scheduling_euler_discrete_karras_fix"] = sched_mod
     pipe_mod = load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans")
     gen_loop(pipe_mod, ref_stock, sched_mod)
+    gen_image_ops(pipe_mod)
 
 
 if __name__ == "__main__":
