@@ -411,17 +411,28 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     int tiles_m = (d->M + BM - 1) / BM;
     long long nwg = (long long)tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) return LKGD_E_SHAPE;
-    // split-K when the tiles fill less than half of the 2-per-CU workgroup slots: slices of >= 4 K-tiles, as many as
-    // the slots and the caller's workspace take (include/lkgd_hip.h: lkgd_gemm_desc.workspace)
+    // split-K when the tiles leave workgroup slots (2 per CU) idle: the smallest slice count whose blocks fill >= 85 % of
+    // the rounds they occupy, slices of >= 4 K-tiles when less than half the slots are filled (few-row problems: the reduce
+    // pass is tiny) and of >= 32 K-tiles otherwise (the 3x3 convs of the full model's 9x16 level: 320 tiles on 512 slots
+    // -> 3 slices, 0.172 -> 0.150 ms; its K = 3840 temporal convs lose more in the reduce pass than they gain);
+    // bounded by the caller's workspace (include/lkgd_hip.h: lkgd_gemm_desc.workspace)
     int ksplit = 1, per = d->K / BK;
     const int nk = d->K / BK;
     const long long slots = 2LL * cus;
-    if (gemm_splitk_enabled && d->workspace && aligned16(d->workspace) && d->N % 4 == 0 && nwg * 2 <= slots && nk >= 8) {
-      long long want = slots / nwg;
-      if (want > nk / 4) want = nk / 4;
-      if (want > 16) want = 16;
+    if (gemm_splitk_enabled && d->workspace && aligned16(d->workspace) && d->N % 4 == 0 && nk >= 8 &&
+        nwg * 10 < slots * 7) {
+      const bool few = nwg * 2 <= slots;
+      const int min_slice = few ? 4 : 32;
+      long long cap = nk / min_slice;
+      if (cap > 16) cap = 16;
       const long long fit = d->workspace_bytes / ((long long)d->M * d->N * 4);
-      if (want > fit) want = fit;
+      if (cap > fit) cap = fit;
+      long long want = 1;
+      for (long long ks = 2; ks <= cap; ++ks) {
+        const long long blocks = nwg * ks, rounds = (blocks + slots - 1) / slots;
+        if (blocks * 100 >= rounds * slots * 85 || (few && ks == cap)) { want = ks; break; }
+      }
+      if (few && slots / nwg > want && slots / nwg <= cap) want = slots / nwg;   // fill one whole round
       if (want >= 2) {
         per = (int)((nk + want - 1) / want);
         ksplit = (nk + per - 1) / per;           // every slice non-empty

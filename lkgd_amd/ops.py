@@ -21,20 +21,11 @@ GEMM_EVENTS = None
 
 #: lkgd_amd.replay.Plan while a kernel sequence is being recorded (every launch below is then also appended to it)
 PLAN = None
-_REC = {}
 
 
 def _L():
-    """the C-ABI library, or its recording stand-in"""
-    real = _lib.lib()
-    if PLAN is None:
-        return real
-    from .replay import _RecordingLib
-    rec = _REC.get(id(PLAN))
-    if rec is None:
-        _REC.clear()
-        rec = _REC[id(PLAN)] = _RecordingLib(real, PLAN)
-    return rec
+    """the C-ABI library, or its recording stand-in while a plan is being recorded"""
+    return PLAN.lib if PLAN is not None else _lib.lib()
 
 
 def _stream() -> int:

@@ -19,6 +19,7 @@ from typing import Callable, List
 import torch
 from torch.overrides import TorchFunctionMode
 
+from . import _lib as _lib_module
 from ._lib import ERRORS, LkgdHipError
 
 
@@ -63,6 +64,7 @@ class Plan:
         self.calls: List[tuple] = []
         self.keep: list = []
         self.result = None
+        self.lib = None          # recording stand-in for the ctypes library (set by `record`)
 
     def python(self, f: Callable[[], None]) -> None:
         """a host-side step (collective, torch copy) to redo at this point of every replay"""
@@ -97,6 +99,7 @@ class record:
         if ops.PLAN is not None:
             raise LkgdHipError("nested recording")
         self.plan = Plan()
+        self.plan.lib = _RecordingLib(_lib_module.lib(), self.plan)
         ops.PLAN = self.plan
         self.mode = _KeepAll(self.plan.keep)
         self.mode.__enter__()
