@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblkgd_hip.so")
+#: LKGD_HIP_LIB points A/B measurements at another build of the same ABI (tools/); the product path is the in-tree build
+LIB_PATH = os.environ.get("LKGD_HIP_LIB") or os.path.join(_HERE, "liblkgd_hip.so")
 
 ERRORS = {-1: "LKGD_E_NULL", -2: "LKGD_E_SHAPE", -3: "LKGD_E_ALIGN", -4: "LKGD_E_MODE", -5: "LKGD_E_LAUNCH"}
 

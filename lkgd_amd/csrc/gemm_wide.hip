@@ -34,7 +34,9 @@
 #define WNT 512
 #define WSTAGE_BYTES ((WBM + WBN) * BK * 2)   // 72 KiB
 #define WBIAS_OFF (2 * WSTAGE_BYTES)          // two 320-float bias strips (tile parity) behind the stages
-#define WLDS (WBIAS_OFF + 2 * WBN * 4)        // 146.5 KiB
+#define WRB_OFF (WBIAS_OFF + 2 * WBN * 4)      // row-bias strips: [tile parity][first | last row's table row][384 halfs]
+#define WRB_STRIP 768
+#define WLDS (WRB_OFF + 4 * WRB_STRIP)        // 149.5 KiB
 
 // ---- K-tile body (generated asm, tools/gen_wide_asm.py).  hipcc's allocator spills a few values of the C++ form of this
 // loop and reloads them next to the LDS-DMA issue; every scratch reload is followed by s_waitcnt vmcnt(0), which in the
@@ -150,6 +152,10 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
   WideIn in;
 #pragma unroll
   for (int i = 0; i < 5; ++i) in.oB[i] = 0;
+  // Row-indexed bias (time embedding / frame position tables): when the row map is piecewise constant over >= 256 rows
+  // (idx = (m / d1) * m1 + c0 mod md with d1 >= 256 - every use but the cross-attention table), a tile's rows select at
+  // most two table rows: those of its first and last token.  Both strips ride the LDS-DMA stream like the bias.
+  const bool rb_lds = p.rowbias && p.rb_d2 == 1 && p.rb_d1 >= WBM;
   const half_t* wbase = (const half_t*)p.w;
   asm volatile("" : "+s"(wbase));            // an opaque SGPR pair: kept (or spilled to a lane), never re-loaded from kernarg
   // move to the next K-tile of the stream (stays on the last one at the end: the loads the uniform K-tile body issues there
@@ -178,6 +184,22 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
           int n = tn * WBN + w * 64 + lane;
           n = n < p.N ? n : p.N - 1;
           __builtin_amdgcn_global_load_lds(GLB_PTR(p.bias + n), LDS_PTR(smem + WBIAS_OFF + st_par * (WBN * 4) + w * 256), 4, 0, 0);
+        }
+        if (rb_lds && w >= 5) {
+          // waves 5-7 fetch dwords (w-5)*64 + lane of the two 160-dword strips (lanes past 160 re-read the last dword
+          // into the strip's padding)
+          const unsigned mf = (unsigned)(tm * WBM);
+          unsigned ml = mf + WBM - 1;
+          ml = ml < (unsigned)p.M ? ml : (unsigned)p.M - 1;
+          const unsigned i0 = ((mf / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (unsigned)p.rb_c0) % (unsigned)p.rb_md;
+          const unsigned i1 = ((ml / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (unsigned)p.rb_c0) % (unsigned)p.rb_md;
+          int dw = (w - 5) * 64 + lane;
+          int col = tn * WBN + 2 * (dw < 160 ? dw : 159);
+          col = col < p.N - 2 ? col : p.N - 2;
+          char* dst = smem + WRB_OFF + st_par * (2 * WRB_STRIP) + (w - 5) * 256;
+          const half_t* rb = (const half_t*)p.rowbias;
+          __builtin_amdgcn_global_load_lds(GLB_PTR(rb + (long long)i0 * p.ldrb + col), LDS_PTR(dst), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(GLB_PTR(rb + (long long)i1 * p.ldrb + col), LDS_PTR(dst + WRB_STRIP), 4, 0, 0);
         }
       }
       if (st_kt * BK >= ag.seg_end) {
@@ -253,13 +275,17 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
       // one token fragment (16 tokens x 160 channels) at a time
       ep_par ^= 1;
       const float* bl = (const float*)(smem + WBIAS_OFF + ep_par * (WBN * 4)) + wc * 160 + 4 * lq;   // bias[n0 + ...]
+      const half_t* rbl = (const half_t*)(smem + WRB_OFF + ep_par * (2 * WRB_STRIP)) + wc * 160 + 4 * lq;
+      // rows below rb_bound use the first strip, the others the second (the map changes at most once inside the tile)
+      const unsigned rb_bound = rb_lds ? ((unsigned)(tm * WBM) / (unsigned)p.rb_d1 + 1u) * (unsigned)p.rb_d1 : 0u;
       auto epi = [&](int j, const float4_t (&e)[10]) {
         const long long m = m0 + j * 16;
         if (m >= p.M) return;
         if (MODE != LKGD_A_PLAIN || !p.geglu) {
           unsigned idx = 0;          // 32-bit row-map arithmetic: M < 2^24 is a launch condition of this kernel
-          if (rbp) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) +
-                          (unsigned)p.rb_c0) % (unsigned)p.rb_md;
+          if (rbp && !rb_lds) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) +
+                                     (unsigned)p.rb_c0) % (unsigned)p.rb_md;
+          const int rb_sel = (unsigned)m < rb_bound ? 0 : WRB_STRIP / 2;
 #pragma unroll
           for (int i = 0; i < 10; ++i) {
             const int n = n0 + i * 16;
@@ -267,7 +293,8 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
               float4_t v = e[i];
               if (p.bias) v += *(const float4_t*)(bl + i * 16);
               if (rbp) {
-                half4_t rb = *(const half4_t*)(rbp + (long long)idx * p.ldrb + n);
+                const half4_t rb = rb_lds ? *(const half4_t*)(rbl + rb_sel + i * 16)
+                                          : *(const half4_t*)(rbp + (long long)idx * p.ldrb + n);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) v[x] += (float)rb[x];
               }

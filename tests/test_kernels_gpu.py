@@ -113,6 +113,26 @@ def test_gemm_rowbias_maps(ops):
         _close(out, ref, what=name)
 
 
+def test_gemm_rowbias_long_periods(ops):
+    """row maps that are constant over >= 256 rows (time embedding per clip, frame position at HW >= 256): the 256x320
+    kernel serves them from two LDS strips per tile - tiles that straddle a boundary, ragged last tile, N = 320 / 640,
+    table rows reached through the modulo, a table that is a column slice of a wider one"""
+    g = torch.Generator().manual_seed(16)
+    for M, N, K, d1, md, c0 in [(700, 320, 64, 300, 1 << 30, 0), (1500, 640, 128, 257, 3, 0), (1024, 320, 64, 256, 2, 1),
+                                (900, 320, 320, 4096, 1 << 30, 0)]:
+        a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+        rows = torch.arange(M)
+        idx = (rows // d1 + c0) % md
+        wide = _h(torch.randn(int(idx.max()) + 1, N + 64, generator=g))
+        table = wide[:, 32:32 + N]
+        bias = torch.randn(N, generator=g)
+        ref = a.float() @ w.float().T + bias + table.float()[idx]
+        out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=bias.to(DEV), rowbias=wide.to(DEV)[:, 32:32 + N],
+                 rowmap=(d1, 1, 1, md, c0))
+        _close(out, ref, what=f"rowbias period {d1} mod {md}")
+
+
 def test_gemm_geglu(ops):
     from lkgd_amd.packing import pack_geglu
     g = torch.Generator().manual_seed(7)
