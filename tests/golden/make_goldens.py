@@ -317,6 +317,35 @@ def gen_unet(ref_stock, ref_lk):
         out["stock_out"].std(), out["stock_out_ctrl"].std(), out["lk_out"].std()))
 
 
+C1_SEED = 31
+
+
+def c1_inputs():
+    """BASELINE.json configs[0] geometry: CFG batch 2 x 4 frames x 32x32 latent, the real SVD channel widths"""
+    g = torch.Generator().manual_seed(C1_SEED + 1)
+    return {"sample": torch.randn(2, 4, 8, 32, 32, generator=g), "t": torch.tensor(1.25),
+            "enc": torch.randn(2, 1, 1024, generator=g), "ids": torch.tensor([[6.0, 127.0, 0.02]] * 2)}
+
+
+def gen_unet_c1(ref_stock):
+    """ONE forward of the reference UNet at its real width (block_out_channels (320,640,1280,1280), heads (5,10,20,20),
+    1.52 B parameters, fp32 on the CPU) on the configs[0] geometry.  Weights: oracle.init_weights_(seed C1_SEED) rounded to
+    fp16 (what the HIP model holds), regenerated from the seed by the test; only inputs, output and a checksum are stored."""
+    from oracle.unet import SVD_CONFIG
+    inp = c1_inputs()
+    with torch.no_grad():
+        m = ref_stock.UNetSpatioTemporalConditionControlNetModel(**SVD_CONFIG.__dict__)
+        ou.init_weights_(m, C1_SEED)
+        for p in m.parameters():
+            p.copy_(p.half().float())
+        out = {"checksum": torch.tensor(checksum(m), dtype=torch.float64),
+               "out": m(inp["sample"], inp["t"], inp["enc"], added_time_ids=inp["ids"], return_dict=False)[0]}
+    for k, v in inp.items():
+        out["in_" + k] = v
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_c1_realwidth.safetensors"))
+    print("unet c1 real width: out std %.4f, checksum %.6e" % (out["out"].std(), out["checksum"]))
+
+
 def gen_controlnet(ref_ctrl, ref_stock):
     """ControlNet-SVD encoder: the reference class over the restated blocks, tiny config"""
     from oracle import controlnet as oc
@@ -554,6 +583,10 @@ def main():
     assert os.path.isdir(REF), "runs only where /root/reference is mounted"
     install_stubs()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "unet_c1":         # only this fixture (6 GB of fp32 weights, ~1 min)
+        gen_unet_c1(load_ref("models/unet_spatio_temporal_condition_controlnet.py",
+                             "models.unet_spatio_temporal_condition_controlnet"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "image_ops":       # only this fixture (the others are unchanged)
         for m in ("models", "utils"):
             _mod(m)
@@ -570,6 +603,7 @@ def main():
                          "models.unet_spatio_temporal_condition_controlnet")
     ref_lk = load_ref("models/unet_spatio_temporal_condition.py", "models.unet_spatio_temporal_condition")
     gen_unet(ref_stock, ref_lk)
+    gen_unet_c1(ref_stock)
     sys.modules["diffusers.models"].UNetSpatioTemporalConditionModel = ref_lk.UNetSpatioTemporalConditionModel
     ref_ctrl = load_ref("models/controlnet_sdv.py", "models.controlnet_sdv")
     gen_controlnet(ref_ctrl, ref_stock)
