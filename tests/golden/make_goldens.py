@@ -579,13 +579,59 @@ def gen_image_ops(pipe_mod):
     print("image_ops:", {k: tuple(v.shape) for k, v in out.items() if not k.endswith("_mean")})
 
 
+def gen_loop_c1(pipe_mod, ref_stock, sched_mod):
+    """BASELINE.json configs[0] end to end through the reference's own pipeline `__call__`: real-width UNet (weights as in
+    gen_unet_c1), 1 clip x 4 frames x 256x256 pixels (32x32 latent), 2 Euler steps, CFG 1 -> 3, output_type="latent"."""
+    from oracle.scheduler import SchedulerConfig
+    from oracle.unet import SVD_CONFIG
+    with torch.no_grad():
+        unet = ref_stock.UNetSpatioTemporalConditionControlNetModel(**SVD_CONFIG.__dict__)
+        ou.init_weights_(unet, C1_SEED)
+        for p in unet.parameters():
+            p.copy_(p.half().float())
+    sched = sched_mod.EulerDiscreteScheduler(**SchedulerConfig().__dict__)
+    fe = lambda images, **k: SimpleNamespace(pixel_values=images)   # noqa: E731
+    pipe = pipe_mod.StableVideoDiffusionPipeline(vae=_FakeVAE(), image_encoder=_FakeCLIP(), unet=unet,
+                                                 scheduler=sched, feature_extractor=fe)
+    g = torch.Generator().manual_seed(C1_SEED + 2)
+    image = torch.rand(1, 3, 256, 256, generator=g)
+    lat0 = torch.randn(1, 4, 4, 32, 32, generator=g)
+    rec, steps = {}, []
+    orig_forward = unet.forward
+
+    def spy(sample, t, **k):
+        if "enc" not in rec:
+            rec["enc"], rec["ids"] = k["encoder_hidden_states"].clone(), k["added_time_ids"].clone()
+            rec["image_latents"] = sample[:, :, 4:].clone()
+        return orig_forward(sample, t, **k)
+    unet.forward = spy
+    res = pipe(image, height=256, width=256, num_frames=4, num_inference_steps=2, latents=lat0.clone(),
+               output_type="latent", generator=torch.Generator().manual_seed(C1_SEED + 3),
+               callback_on_step_end=lambda p, i, t, kw_: (steps.append(kw_["latents"].clone()), {})[1])
+    out = {"latents0": lat0, "final": res.frames, "image_embeddings": rec["enc"], "added_time_ids": rec["ids"],
+           "image_latents": rec["image_latents"].contiguous(), "step_latents": torch.stack(steps),
+           "checksum": torch.tensor(checksum(unet), dtype=torch.float64)}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "loop_c1_realwidth.safetensors"))
+    print("loop c1 real width: final std %.4f (2 steps)" % out["final"].std())
+
+
 def main():
     assert os.path.isdir(REF), "runs only where /root/reference is mounted"
     install_stubs()
     sys.path.insert(0, REF)
-    if len(sys.argv) > 1 and sys.argv[1] == "unet_c1":         # only this fixture (6 GB of fp32 weights, ~1 min)
-        gen_unet_c1(load_ref("models/unet_spatio_temporal_condition_controlnet.py",
-                             "models.unet_spatio_temporal_condition_controlnet"))
+    if len(sys.argv) > 1 and sys.argv[1] in ("unet_c1", "loop_c1"):   # only these fixtures (6 GB of fp32 weights, ~1 min each)
+        for m in ("models", "utils"):
+            _mod(m)
+        sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
+        ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
+                             "models.unet_spatio_temporal_condition_controlnet")
+        if sys.argv[1] == "unet_c1":
+            gen_unet_c1(ref_stock)
+        else:
+            sys.modules["models.unet_spatio_temporal_condition_controlnet"] = ref_stock
+            sys.modules["utils.scheduling_euler_discrete_karras_fix"] = sched_mod
+            gen_loop_c1(load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans"), ref_stock,
+                        sched_mod)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "image_ops":       # only this fixture (the others are unchanged)
         for m in ("models", "utils"):
@@ -626,6 +672,7 @@ def main():
     sys.modules["utils.scheduling_euler_discrete_karras_fix"] = sched_mod
     pipe_mod = load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans")
     gen_loop(pipe_mod, ref_stock, sched_mod)
+    gen_loop_c1(pipe_mod, ref_stock, sched_mod)
     gen_image_ops(pipe_mod)
 
 

@@ -28,31 +28,56 @@ def golden(golden_dir):
     return load_file(os.path.join(golden_dir, "unet_c1_realwidth.safetensors"))
 
 
-def test_oracle_real_width_vs_reference_golden(golden):
-    """pins the oracle at the real channel widths / head counts (the tiny-config wiring goldens cannot see e.g. a
-    heads-per-level mistake): same weights (checksum), same output to fp32 summation-order noise"""
-    o = _oracle_model()
-    ck = float(sum(p.detach().double().abs().sum() for p in o.parameters()))
-    assert abs(ck - golden["checksum"].item()) <= 1e-9 * golden["checksum"].item()
-    with torch.no_grad():
-        out = o(golden["in_sample"], golden["in_t"], golden["in_enc"], added_time_ids=golden["in_ids"], return_dict=False)[0]
-    ref = golden["out"]
-    rel = ((out - ref).norm() / ref.norm()).item()
-    assert rel < 1e-4, rel
+@pytest.fixture(scope="module")
+def loop_golden(golden_dir):
+    return load_file(os.path.join(golden_dir, "loop_c1_realwidth.safetensors"))
 
 
-@pytest.mark.gpu
-def test_hip_real_width_unet_vs_reference_golden(golden):
+@pytest.fixture(scope="module")
+def oracle_model():
+    return _oracle_model()
+
+
+@pytest.fixture(scope="module")
+def hip_model(oracle_model):
     from lkgd_amd import unet as pu
-    o = _oracle_model()
-    ck = float(sum(p.detach().double().abs().sum() for p in o.parameters()))
-    assert abs(ck - golden["checksum"].item()) <= 1e-9 * golden["checksum"].item()
     with torch.device("meta"):
         m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig())
     m = m.to_empty(device="cpu")
-    m.load_state_dict(o.state_dict(), strict=True)
-    del o
-    m = m.half().to("cuda:0")
+    m.load_state_dict(oracle_model.state_dict(), strict=True)
+    return m.half().to("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def test_oracle_real_width_vs_reference_golden(golden, loop_golden, oracle_model):
+    """pins the oracle at the real channel widths / head counts (the tiny-config wiring goldens cannot see e.g. a
+    heads-per-level mistake): same weights (checksum), same output to fp32 summation-order noise - one forward, and the
+    2-step loop of the reference's own pipeline `__call__` (BASELINE.json configs[0])"""
+    from oracle.loop import denoise
+    from oracle.scheduler import EulerDiscreteOracle
+    o = oracle_model
+    ck = float(sum(p.detach().double().abs().sum() for p in o.parameters()))
+    assert abs(ck - golden["checksum"].item()) <= 1e-9 * golden["checksum"].item()
+    assert abs(ck - loop_golden["checksum"].item()) <= 1e-9 * ck
+    with torch.no_grad():
+        out = o(golden["in_sample"], golden["in_t"], golden["in_enc"], added_time_ids=golden["in_ids"], return_dict=False)[0]
+        assert _rel(out, golden["out"]) < 1e-4
+        g = loop_golden
+        steps = []
+        fin = denoise(o, EulerDiscreteOracle(), g["latents0"], g["image_latents"], g["image_embeddings"],
+                      g["added_time_ids"], 2, callback=lambda i, t, lat: steps.append(lat.clone()))
+    assert _rel(fin, g["final"]) < 1e-4
+    if steps:
+        assert _rel(steps[0], g["step_latents"][0]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_real_width_unet_vs_reference_golden(golden, hip_model):
+    m = hip_model
     out = m(golden["in_sample"].cuda(), golden["in_t"].cuda(), golden["in_enc"].cuda(),
             added_time_ids=golden["in_ids"].cuda(), return_dict=False)[0]
     got, ref = out.float().cpu(), golden["out"]
@@ -60,3 +85,21 @@ def test_hip_real_width_unet_vs_reference_golden(golden):
     mx = (got - ref).abs().max().item()
     assert torch.isfinite(got).all()
     assert rel <= 1e-2 and mx <= 5e-2, f"real-width UNet vs the reference forward: rel L2 {rel:.3e}, max abs {mx:.3e}"
+
+
+@pytest.mark.gpu
+def test_hip_real_width_loop_vs_reference_pipeline_golden(loop_golden, hip_model):
+    """BASELINE.json configs[0] through `pipeline.__call__`: every step's latents and the final latents of the reference's
+    fp32 CPU run (2 Euler steps, CFG 1 -> 3, 4 frames, 32x32 latent); gate rel L2 <= 2e-2 (fp16 loop vs fp32 loop)"""
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+    g = loop_golden
+    pipe = StableVideoDiffusionPipeline(unet=hip_model)
+    steps = []
+    out = pipe(None, height=256, width=256, num_frames=4, num_inference_steps=2, latents=g["latents0"],
+               output_type="latent", image_embeddings=g["image_embeddings"], image_latents=g["image_latents"].half(),
+               fps=7, motion_bucket_id=127, noise_aug_strength=0.02,
+               callback_on_step_end=lambda p, i, t, kw: (steps.append(kw["latents"].clone()), {})[1])
+    assert out.frames.shape == g["final"].shape and torch.isfinite(out.frames.float()).all()
+    for i, st in enumerate(steps):
+        assert _rel(st, g["step_latents"][i]) < 2e-2, i
+    assert _rel(out.frames, g["final"]) < 2e-2
