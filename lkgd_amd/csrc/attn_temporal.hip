@@ -4,16 +4,20 @@
 // reference is this kernel's index map; nothing is copied.
 //
 // A workgroup (8 pairs x 16 or 32 query-frame slots) owns 8 adjacent (pixel, head) pairs:
-//   1. Q, K, V of the 8 pairs x F frames are staged into LDS with fully coalesced 16-byte loads (adjacent pairs are
-//      adjacent 128-byte head segments) - every byte crosses HBM / L2 exactly once;
-//   2. thread (pair p, query frame fq) computes its 64-wide output row from LDS: K/V rows are shared by the query threads
-//      of a pair (LDS broadcast); the pair stride is padded to 144 B so the 8 pairs of a wave hit disjoint banks;
-//      scores by v_dot2_f32_f16, softmax in registers (exp2 with the scale folded in), P.V in fp32;
-//   3. the output rows go back through LDS and leave as coalesced 16-byte stores.
+//   1. K and V of the 8 pairs x F frames go to LDS by LDS-DMA (global_load_lds_dwordx4): one instruction moves one
+//      (tensor, frame) plane = 8 pairs x 128 B (adjacent pairs are adjacent 128-byte head segments), all 2F planes of
+//      the workgroup are in flight at once - one HBM round trip per workgroup, no staging registers; the 16-byte chunk
+//      a lane fetches is XOR-ed with its pair index (source-side swizzle) so the 8 pairs of a wave read disjoint banks;
+//   2. thread (pair p, query frame fq) loads ITS query row straight into registers and computes its 64-wide output row:
+//      K/V rows are shared by the query threads of a pair (LDS broadcast); scores by v_dot2_f32_f16, softmax in
+//      registers (exp2 with the scale folded in), P.V in fp32;
+//   3. the output row (128 contiguous bytes per thread) is stored directly.
+// 28 KiB of LDS per workgroup at F = 14 -> five workgroups per CU keep loads, arithmetic and stores of different
+// workgroups overlapped.
 #include "common.h"
 
 #define TP 8                 // pairs per workgroup
-#define TPAD 144             // bytes per (frame, pair) row in LDS: 128 + 16 (bank spread)
+#define TROW 128             // bytes per (frame, pair) row in LDS (chunk c of pair p lives in 16-byte slot c ^ p)
 
 template <int FMAX>
 __global__ __launch_bounds__(FMAX * TP) void attn_temporal_kernel(const half_t* __restrict__ q, int ldq,
@@ -29,70 +33,59 @@ __global__ __launch_bounds__(FMAX * TP) void attn_temporal_kernel(const half_t* 
   const int kvb = kvmap ? kvmap[b] : b;
   const long long npairs = (long long)S * heads;
   const long long pid0 = (long long)blockIdx.x * TP;
-  constexpr int plane = TP * TPAD;             // bytes per frame
-  char* sq = smem;                             // [Fq][TP][144]
-  char* sk = sq + Fq * plane;                  // [F ][TP][144]
+  constexpr int plane = TP * TROW;             // bytes per (tensor, frame) plane: one LDS-DMA instruction
+  char* sk = smem;                             // [F][TP][128]
   char* sv = sk + F * plane;
+  const int pp = t & (TP - 1), fq = t >> 3;
 
-  // ---- 1. coalesced staging: chunk id -> (tensor, frame, pair, 16-byte chunk); loads are issued in batches of 8 per
-  //         thread before any of them is consumed, so a thread keeps 8 x 16 B in flight instead of one
-  const int nq = Fq * TP * 8, nkv = F * TP * 8;
-  const int nall = nq + 2 * nkv;
-  for (int base = 0; base < nall; base += 8 * NT) {
-    uint4 r0, r1, r2, r3, r4, r5, r6, r7;
-    int d0, d1, d2, d3, d4, d5, d6, d7;
-#define TLOAD(U, R, D)                                                                                   \
-    {                                                                                                      \
-      int id = base + (U) * NT + t;                                                                        \
-      const bool ok = id < nall;                                                                           \
-      if (!ok) id = nall - 1;                                                                              \
-      const int tensor = id < nq ? 0 : (id < nq + nkv ? 1 : 2);                                            \
-      const int r = id - (tensor == 0 ? 0 : (tensor == 1 ? nq : nq + nkv));                                \
-      const int c = r & 7, pp = (r >> 3) & (TP - 1), f = r >> 6;                                           \
-      long long pid = pid0 + pp;                                                                           \
-      if (pid >= npairs) pid = npairs - 1;                                                                 \
-      const int s = (int)(pid / heads), hh = (int)(pid - (long long)s * heads);                            \
-      const half_t* src = tensor == 0 ? q + (((long long)b * Fq + f) * S + s) * ldq                        \
-                          : tensor == 1 ? k + (((long long)kvb * F + f) * S + s) * ldk                     \
-                                        : v + (((long long)kvb * F + f) * S + s) * ldv;                    \
-      const int off = tensor == 0 ? 0 : (tensor == 1 ? Fq * plane : (Fq + F) * plane);                     \
-      R = *(const uint4*)(src + hh * 64 + c * 8);                                                          \
-      D = ok ? off + f * plane + pp * TPAD + c * 16 : -1;                                                  \
-    }
-    TLOAD(0, r0, d0) TLOAD(1, r1, d1) TLOAD(2, r2, d2) TLOAD(3, r3, d3)
-    TLOAD(4, r4, d4) TLOAD(5, r5, d5) TLOAD(6, r6, d6) TLOAD(7, r7, d7)
-#undef TLOAD
-    if (d0 >= 0) *(uint4*)(smem + d0) = r0;
-    if (d1 >= 0) *(uint4*)(smem + d1) = r1;
-    if (d2 >= 0) *(uint4*)(smem + d2) = r2;
-    if (d3 >= 0) *(uint4*)(smem + d3) = r3;
-    if (d4 >= 0) *(uint4*)(smem + d4) = r4;
-    if (d5 >= 0) *(uint4*)(smem + d5) = r5;
-    if (d6 >= 0) *(uint4*)(smem + d6) = r6;
-    if (d7 >= 0) *(uint4*)(smem + d7) = r7;
+  // ---- 1a. this thread's query row -> registers (issued first: it is consumed first)
+  long long my_pid = pid0 + pp;
+  const bool pair_ok = my_pid < npairs;
+  if (!pair_ok) my_pid = npairs - 1;
+  const int my_s = (int)(my_pid / heads), my_h = (int)(my_pid - (long long)my_s * heads);
+  half8_t qv[8];
+  {
+    const int fqc = fq < Fq ? fq : Fq - 1;
+    const half_t* qp = q + (((long long)b * Fq + fqc) * S + my_s) * ldq + my_h * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = *(const half8_t*)(qp + i * 8);
   }
+  // ---- 1b. K / V planes by LDS-DMA: wave w takes planes w, w + nw, ...; lane = (pair lp, slot ls) fetches chunk ls ^ lp
+  {
+    const int lane = t & 63, w = t >> 6;
+    constexpr int nw = NT / 64;
+    const int lp = lane >> 3, ls = lane & 7;
+    long long pid = pid0 + lp;
+    if (pid >= npairs) pid = npairs - 1;
+    const int s = (int)(pid / heads), hh = (int)(pid - (long long)s * heads);
+    const long long koff = (long long)s * ldk + hh * 64 + ((ls ^ lp) << 3);
+    const long long voff = (long long)s * ldv + hh * 64 + ((ls ^ lp) << 3);
+    for (int j = w; j < 2 * F; j += nw) {
+      const int f = j < F ? j : j - F;
+      const half_t* src = j < F ? k + ((long long)kvb * F + f) * S * ldk + koff
+                                : v + ((long long)kvb * F + f) * S * ldv + voff;
+      glds16(src, smem + j * plane);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ---- 2. one thread = one (pair, query frame) row
-  const int pp = t & (TP - 1), fq = t >> 3;
   float o[64];
 #pragma unroll
   for (int d = 0; d < 64; ++d) o[d] = 0.f;
   if (fq < Fq) {
-    half8_t qv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qv[i] = *(const half8_t*)(sq + fq * plane + pp * TPAD + i * 16);
     float sc[FMAX];
     float mx = -1e30f;
 #pragma unroll
     for (int f = 0; f < FMAX; ++f) {
       sc[f] = -1e30f;
       if (f < F) {
-        const char* kp = sk + f * plane + pp * TPAD;
+        const char* kp = sk + f * plane + pp * TROW;
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          half8_t kv = *(const half8_t*)(kp + i * 16);
+          half8_t kv = *(const half8_t*)(kp + ((i ^ pp) << 4));
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             half2_t a = {qv[i][2 * e], qv[i][2 * e + 1]};
@@ -113,37 +106,38 @@ __global__ __launch_bounds__(FMAX * TP) void attn_temporal_kernel(const half_t* 
       l += p;
     }
     const float inv = 1.0f / l;
+    // P.V two frames at a time: o[d] += dot2((v[f][d], v[f+1][d]), (p[f], p[f+1])) - one pack + one v_dot2_f32_f16 per
+    // frame pair instead of two converts + two FMAs (fp16 products are exact in fp32, the accumulator stays fp32)
 #pragma unroll
-    for (int f = 0; f < FMAX; ++f) {
+    for (int f = 0; f < FMAX; f += 2) {
       if (f < F) {
-        const char* vp = sv + f * plane + pp * TPAD;
+        const bool two = f + 1 < F;
+        const char* vp0 = sv + f * plane + pp * TROW;
+        const char* vp1 = two ? vp0 + plane : vp0;
         // SDPA rounds the probabilities to the compute dtype before P.V
-        const float p = (float)(half_t)(sc[f] * inv);
+        const half2_t p2 = {(half_t)(sc[f] * inv), two ? (half_t)(sc[f + 1] * inv) : (half_t)0.f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          half8_t vv = *(const half8_t*)(vp + i * 16);
+          const half8_t v0 = *(const half8_t*)(vp0 + ((i ^ pp) << 4));
+          const half8_t v1 = *(const half8_t*)(vp1 + ((i ^ pp) << 4));
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[i * 8 + e] = fmaf(p, (float)vv[e], o[i * 8 + e]);
+          for (int e = 0; e < 8; ++e) {
+            const half2_t vv = {v0[e], v1[e]};
+            o[i * 8 + e] = __builtin_amdgcn_fdot2(vv, p2, o[i * 8 + e], false);
+          }
         }
       }
     }
-    // ---- 3. outputs through LDS (the Q region: a thread overwrites only the q row it alone has consumed)
+    // ---- 3. the output row: 128 contiguous bytes per thread
+    if (pair_ok) {
+      half_t* op = out + (((long long)b * Fq + fq) * S + my_s) * ldo + my_h * 64;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      half8_t ov;
+      for (int i = 0; i < 8; ++i) {
+        half8_t ov;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ov[e] = (half_t)o[i * 8 + e];
-      *(half8_t*)(sq + fq * plane + pp * TPAD + i * 16) = ov;
-    }
-  }
-  __syncthreads();
-  for (int id = t; id < nq; id += NT) {
-    const int c = id & 7, p2 = (id >> 3) & (TP - 1), f = id >> 6;
-    const long long pid = pid0 + p2;
-    if (pid < npairs) {
-      const int s = (int)(pid / heads), hh = (int)(pid - (long long)s * heads);
-      *(uint4*)(out + (((long long)b * Fq + f) * S + s) * ldo + hh * 64 + c * 8) =
-          *(const uint4*)(sq + f * plane + p2 * TPAD + c * 16);
+        for (int e = 0; e < 8; ++e) ov[e] = (half_t)o[i * 8 + e];
+        *(half8_t*)(op + i * 8) = ov;
+      }
     }
   }
 }
@@ -163,16 +157,16 @@ extern "C" int lkgd_attn_temporal(const void* q, int32_t ldq, const void* k, int
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)attn_temporal_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            3 * 32 * TP * TPAD) != hipSuccess)
+                            2 * 32 * TP * TROW) != hipSuccess)
       return LKGD_E_LAUNCH;
     attr_set = true;
   }
   if (F <= 16)
-    hipLaunchKernelGGL(attn_temporal_kernel<16>, dim3((unsigned)nblk, B), dim3(16 * TP), (Fq + 2 * F) * TP * TPAD,
+    hipLaunchKernelGGL(attn_temporal_kernel<16>, dim3((unsigned)nblk, B), dim3(16 * TP), 2 * F * TP * TROW,
                        (hipStream_t)stream, (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv,
                        (half_t*)out, ldo, Fq, F, S, heads, kv_b_map, c);
   else
-    hipLaunchKernelGGL(attn_temporal_kernel<32>, dim3((unsigned)nblk, B), dim3(32 * TP), (Fq + 2 * F) * TP * TPAD,
+    hipLaunchKernelGGL(attn_temporal_kernel<32>, dim3((unsigned)nblk, B), dim3(32 * TP), 2 * F * TP * TROW,
                        (hipStream_t)stream, (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv,
                        (half_t*)out, ldo, Fq, F, S, heads, kv_b_map, c);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
