@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, int c0,
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-#pragma unroll 4
-    for (long long r = r0 + rp; r < r1; r += mp.rows_par) {
+#pragma unroll 8
+    for (long long r = r0 + rp; r < r1; r += mp.rows_par) {      // 8 x 16 B in flight per thread
       half8_t v = gn_load(x0, c0, ld0, x1, ld1, base + r, cv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { float f = (float)v[e]; s[e] += f; q[e] += f * f; }
