@@ -316,8 +316,11 @@ __device__ __forceinline__ void gemm_epilogue(const lkgd_gemm_desc& p, const flo
         float4_t v = *(const float4_t*)(ct + row * BN_ + col);
         v += bias;
         if (rbp) {
-          long long idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
-          half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + gcol);
+          // M is an int32: 32-bit unsigned row-map arithmetic (a 64-bit division is a few hundred instructions)
+          const unsigned mu = (unsigned)m;
+          const unsigned idx = ((mu / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (mu % (unsigned)p.rb_d2) +
+                                (unsigned)p.rb_c0) % (unsigned)p.rb_md;
+          half4_t rb = *(const half4_t*)(rbp + (long long)idx * p.ldrb + gcol);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
         }

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(PNT) void lkgd_gemm_pp_kernel(const lkgd_gemm_desc 
         }
         const long long m = mb + l31;
         long long idx = 0;
-        if (rbp && m < p.M) idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
+        if (rbp && m < p.M) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) + (unsigned)p.rb_c0) % (unsigned)p.rb_md;   // M is an int32
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll

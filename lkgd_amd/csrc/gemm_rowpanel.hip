@@ -132,7 +132,7 @@ __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd
         }
       }
       long long idx = 0;
-      if (rbp && mrow < p.M) idx = ((mrow / p.rb_d1) * p.rb_m1 + (mrow % p.rb_d2) + p.rb_c0) % p.rb_md;
+      if (rbp && mrow < p.M) idx = (((unsigned)mrow / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)mrow % (unsigned)p.rb_d2) + (unsigned)p.rb_c0) % (unsigned)p.rb_md;   // M is an int32
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll

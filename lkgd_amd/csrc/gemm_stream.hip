@@ -218,7 +218,7 @@ __global__ __launch_bounds__(SNT, 2) void lkgd_gemm_stream_kernel(const lkgd_gem
         for (int j = 0; j < 2; ++j) {
           const long long m = m0 + j * 32 + l31;
           long long idx = 0;
-          if (rbp && m < p.M) idx = ((m / p.rb_d1) * p.rb_m1 + (m % p.rb_d2) + p.rb_c0) % p.rb_md;
+          if (rbp && m < p.M) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) + (unsigned)p.rb_c0) % (unsigned)p.rb_md;   // M is an int32
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll

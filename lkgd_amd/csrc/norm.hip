@@ -286,7 +286,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx
     float xv[LN_MAXV][8];
     float s = 0.f;
     long long idx = 0;
-    if (rowbias && live) idx = ((row / d1) * m1 + (row % d2) + c0) % md;
+    if (rowbias && live) {
+      if (T < (1LL << 31)) {   // the usual case: 32-bit unsigned arithmetic (64-bit divisions cost more than the norm itself)
+        const unsigned ru = (unsigned)row;
+        idx = ((ru / (unsigned)d1) * (unsigned)m1 + (ru % (unsigned)d2) + (unsigned)c0) % (unsigned)md;
+      } else {
+        idx = ((row / d1) * m1 + (row % d2) + c0) % md;
+      }
+    }
 #pragma unroll
     for (int v = 0; v < LN_MAXV; ++v) {
       int cv = li + L * v;
