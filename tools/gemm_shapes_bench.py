@@ -40,7 +40,7 @@ def shapes():
         H, W, C = LEVELS[lv]
         M = N_IMG * H * W
         out.append((f"lin L{lv} proj/out {C}x{C}", cnt * 4, "lin", dict(M=M, N=C, K=C)))
-        out.append((f"lin L{lv} qkv {3*C}x{C}", cnt * 2, "lin", dict(M=M, N=3 * C, K=C)))
+        out.append((f"lin L{lv} qkv {3*C}x{C}", cnt * 2, "lin", dict(M=M, N=3 * C, K=C, plain=True)))   # no bias, no residual
         out.append((f"lin L{lv} geglu {8*C}x{C}", cnt * 3, "geglu", dict(M=M, N=8 * C, K=C)))
         out.append((f"lin L{lv} ffout {C}x{4*C}", cnt * 3, "lin", dict(M=M, N=C, K=4 * C)))
     return out
@@ -71,8 +71,8 @@ def run(kind, d, iters=5, variants=None):
         a, w = z(M, K), z(N, K)
         geglu = kind == "geglu"
         out = torch.empty(M, N // 2 if geglu else N, device=DEV, dtype=torch.float16)
-        bias = torch.zeros(N, device=DEV)
-        res = None if (geglu or os.environ.get('NORES')) else torch.zeros(M, N, device=DEV, dtype=torch.float16)
+        bias = None if d.get("plain") else torch.zeros(N, device=DEV)
+        res = None if (geglu or d.get("plain") or os.environ.get('NORES')) else torch.zeros(M, N, device=DEV, dtype=torch.float16)
         from lkgd_amd.packing import geglu_half
         gw = [geglu_half(N, K)]       # interleave width; the forced 256x320 variant runs its own 80-wide packing
         fn = lambda: ops.gemm(a, w, out, M=M, N=N, K=K, bias=bias, geglu=gw[0] if geglu else 0, res1=res)   # noqa

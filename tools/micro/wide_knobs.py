@@ -27,7 +27,9 @@ M0 = 28 * 72 * 128
 for (name, M, N, K, geglu, res) in (("L0 geglu", M0, 2560, 320, True, False), ("L0 ffout", M0, 320, 1280, False, True),
                                     ("L0 qkv", M0, 960, 320, False, False), ("L1 geglu", M0 // 4, 5120, 640, True, False),
                                     ("L2 ffout", M0 // 16, 1280, 5120, False, True),
-                                    ("deep K", 32768, 2560, 5120, False, False)):
+                                    ("deep K", 32768, 2560, 5120, False, False),
+                                    ("L1 qkv", M0 // 4, 1920, 640, False, False), ("L1 proj", M0 // 4, 640, 640, False, True),
+                                    ("L2 qkv", M0 // 16, 3840, 1280, False, False)):
     a = torch.randn(M, K, device=DEV, dtype=torch.float16) * 0.1
     w = torch.randn(N, K, device=DEV, dtype=torch.float16) * 0.1
     # (GEGLU weights would be row-permuted by lkgd_amd.packing; irrelevant for the time)
