@@ -318,6 +318,7 @@ static int check_desc(const lkgd_gemm_desc* d) {
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_wide.hip
+extern "C" int lkgd_gemm_wide4_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);    // gemm_wide4.hip
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
 extern "C" int lkgd_gemm_pp_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);       // gemm_pp.hip
 
@@ -370,7 +371,7 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide, 5 = rowpanel, 6 = ping-pong
   if (d->geglu == 80) {
     if (!wide_ok) return LKGD_E_SHAPE;
-    pick = 4;                                            // 80-wide GEGLU interleave exists only in the 256x320 kernel
+    pick = v == 7 ? 7 : 4;                                            // 80-wide GEGLU interleave exists only in the 256x320 kernel
   } else if (v != 0) {
     pick = v;
   } else if (rp_ok && d->M >= 4096 && d->K >= 192 && (d->N != 320 || d->res1)) {
@@ -389,12 +390,13 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   // applicability (forced variants fall back the same way)
   if (pick == 5 && !rp_ok) pick = 1;
   if (pick == 6 && !pp_ok) pick = 3;
-  if (pick == 4 && !wide_ok) pick = 3;
+  if ((pick == 4 || pick == 7) && !wide_ok) pick = 3;
   if (pick == 3 && (!stream_ok || d->M <= 256)) pick = (d->K >= 960 && d->M > 256) ? 2 : 1;
-  if (d->geglu == 80 && pick != 4) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the wide kernel
+  if (d->geglu == 80 && pick != 4 && pick != 7) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the 256x320 kernels
   if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
   if (pick == 6) return lkgd_gemm_pp_launch(d, (hipStream_t)stream, cus);
   if (pick == 4) return lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus);
+  if (pick == 7) return lkgd_gemm_wide4_launch(d, (hipStream_t)stream, cus);
   if (pick == 3) return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
   int tiles_n = (d->N + BN - 1) / BN;
   // deep-K problems (3x3 / temporal convs, K >= 960) take the 256x128 three-stage ring: its two K-tiles in flight hide

@@ -16,7 +16,7 @@ import torch
 from lkgd_amd import _lib
 _lib.LIB_PATH = sys.argv[1]
 from lkgd_amd import ops
-_lib.lib().lkgd_debug_set_gemm_variant(4)
+_lib.lib().lkgd_debug_set_gemm_variant(int(os.environ.get('VARIANT', '4')))
 DEV = "cuda:0"
 a0 = torch.randn(8192, 8192, device=DEV, dtype=torch.float16)
 t0 = time.time()
@@ -47,6 +47,9 @@ for (name, M, N, K, geglu, res) in (("L0 geglu", M0, 2560, 320, True, False), ("
     print("  %%-9s %%7dx%%5dx%%5d  %%7.3f ms  %%7.1f TF/s" %% (name, M, N, K, best, 2.0 * M * N * K / best / 1e9))
 ''' % REPO
 
+if "--single" in sys.argv:          # tools/micro/lib_ab.py: time the library LKGD_HIP_LIB points at
+    subprocess.run([sys.executable, "-c", CHILD, os.environ["LKGD_HIP_LIB"]], check=False)
+    sys.exit(0)
 for lib in sorted(glob.glob(os.path.join(HERE, "libwide_*.so"))):
     print(os.path.basename(lib), flush=True)
     subprocess.run([sys.executable, "-c", CHILD, lib], check=False)

@@ -7,9 +7,12 @@ cd "$(dirname "$0")/../../lkgd_amd/csrc"
 make -s
 OBJS=""
 for s in gemm gemm_stream gemm_rowpanel gemm_pp norm attn_spatial attn_temporal elementwise fsm conv_small image_ops; do OBJS="$OBJS $s.o"; done
-for knob in BASE NOSTORE NOSTAGE NOMFMA "$@"; do
+KERNEL=${KERNEL:-gemm_wide}      # KERNEL=gemm_wide4 builds the knob variants of the four-wave kernel instead
+OTHER=$([ "$KERNEL" = gemm_wide ] && echo gemm_wide4 || echo gemm_wide)
+OBJS="$OBJS $OTHER.o"
+for knob in BASE NOSTAGE NOREAD NOMFMA NOBAR "$@"; do
   tag=${knob/=/}
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm -DWIDE_X_$knob -c gemm_wide.hip -o /tmp/gemm_wide_$tag.o
-  hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/gemm_wide_$tag.o -o ../../tools/micro/libwide_$tag.so
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm -DWIDE_X_$knob -c $KERNEL.hip -o /tmp/${KERNEL}_$tag.o
+  hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/${KERNEL}_$tag.o -o ../../tools/micro/libwide_$tag.so
 done
 ls -la ../../tools/micro/libwide_*.so
