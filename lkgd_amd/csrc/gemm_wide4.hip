@@ -241,9 +241,13 @@ __global__ __launch_bounds__(WNT, 1) __attribute__((amdgpu_num_vgpr(WIDE4_VC))) 
     const int m_a = (cur ^ 1) * WSTAGE_BYTES + w * 1024;
     if (kt == 0) wide4_ktile_a<true>(xa0, xa1, wa0, wa1, ag.aptr, m_a);
     else wide4_ktile_a<false>(xa0, xa1, wa0, wa1, ag.aptr, m_a);
+#ifndef WIDE_X_NONEXT             /* timing knob: sources never advance (wrong results) */
     next_a();                   // K-tile s+2's A-row sources, while K-step 0's MFMAs drain
+#endif
     wide4_ktile_b(wa1, in, m_a);
+#ifndef WIDE_X_NONEXT
     next_w(in);                 // ... and its weight-row sources
+#endif
     {
       const int d = cur ? -WSTAGE_BYTES : WSTAGE_BYTES;      // the other stage becomes the current one
       xa0 += d; xa1 += d; wa0 += d; wa1 += d;

@@ -10,7 +10,7 @@ for s in gemm gemm_stream gemm_rowpanel gemm_pp norm attn_spatial attn_temporal 
 KERNEL=${KERNEL:-gemm_wide}      # KERNEL=gemm_wide4 builds the knob variants of the four-wave kernel instead
 OTHER=$([ "$KERNEL" = gemm_wide ] && echo gemm_wide4 || echo gemm_wide)
 OBJS="$OBJS $OTHER.o"
-for knob in BASE NOSTAGE NOREAD NOMFMA NOBAR "$@"; do
+for knob in BASE NONEXT NOBAR "$@"; do
   tag=${knob/=/}
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm -DWIDE_X_$knob -c $KERNEL.hip -o /tmp/${KERNEL}_$tag.o
   hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/${KERNEL}_$tag.o -o ../../tools/micro/libwide_$tag.so
