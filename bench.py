@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="tiny UNet config (plumbing checks only; not a valid number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--lk", action="store_true",
+                    help="configs[2]: the LKGD UNet (UNetSpatioTemporalConditionModel) with domain / flow features fused into the "
+                         "CLIP embedding (not the headline workload)")
     ap.add_argument("--controlnet", action="store_true",
                     help="also run the ControlNet-SVD encoder every step (SURVEY.md 8f rank 1; not the headline workload)")
     return ap.parse_args()
@@ -62,7 +65,7 @@ def synthetic_inputs(dev, frames, h, w):
     return lat0.to(dev), img.half().to(dev).contiguous(), emb.half().to(dev), ids.to(dev)
 
 
-def build_unet(dev, tiny):
+def build_unet(dev, tiny, lk=False):
     from lkgd_amd import unet as pu
     if tiny:
         cfg = pu.UNetConfig(sample_size=8, block_out_channels=(64, 128, 128, 128), num_attention_heads=(1, 2, 2, 2),
@@ -70,7 +73,7 @@ def build_unet(dev, tiny):
     else:
         cfg = pu.UNetConfig()
     with torch.device("meta"):
-        m = pu.UNetSpatioTemporalConditionControlNetModel(cfg)
+        m = (pu.UNetSpatioTemporalConditionModel if lk else pu.UNetSpatioTemporalConditionControlNetModel)(cfg)
     m = m.to(torch.float16).to_empty(device=dev)
     pu.init_synthetic_weights_(m, seed=0)
     m.prepare()
@@ -147,8 +150,14 @@ def main():
     from lkgd_amd.pipeline import StableVideoDiffusionPipeline
 
     h, w = args.height // 8, args.width // 8
-    unet = build_unet(dev, args.tiny)
+    unet = build_unet(dev, args.tiny, args.lk)
     pipe = StableVideoDiffusionPipeline(unet=unet)
+    dom = flow = None
+    if args.lk:
+        if distributed:
+            raise SystemExit("--lk is a single-GPU option")
+        dom = torch.randn(1, 1, 1000, generator=torch.Generator().manual_seed(12348)).half().to(dev)
+        flow = torch.randn(1, 1, 1000, generator=torch.Generator().manual_seed(12349)).half().to(dev)
     lat0, img, emb, ids = synthetic_inputs(dev, args.frames, h, w)
     ctrl_cond = None
     if args.controlnet:
@@ -176,7 +185,7 @@ def main():
     else:
         def one_clip():
             return pipe.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0,
-                                controlnet_condition=ctrl_cond)
+                                domain_features=dom, flow_features=flow, controlnet_condition=ctrl_cond)
 
     def barrier():
         if distributed:
@@ -235,6 +244,7 @@ def main():
                                    f"{args.inference_steps} Euler steps, CFG 1.0->3.0, single clip, "
                                    + ("ControlNet pipeline loop (pipeline_stable_video_diffusion_controlnet, NOT the headline)"
                                       if args.controlnet else
+                                      "LKGD UNet with domain / flow features (configs[2], NOT the headline)" if args.lk else
                                       "vanilla pipeline_stable_video_diffusion_trans loop (configs[1])")
                                    + (" [TINY UNET - INVALID]" if args.tiny else ""),
                        "unet": "random-init SVD shapes (320,640,1280,1280), heads (5,10,20,20), 1.52 B params",
