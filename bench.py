@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--lk", action="store_true",
                     help="configs[2]: the LKGD UNet (UNetSpatioTemporalConditionModel) with domain / flow features fused into the "
                          "CLIP embedding (not the headline workload)")
+    ap.add_argument("--joint", action="store_true",
+                    help="the `patch` joint-attention hooks (utils/util.py:561-606): TWO clips per call (the [start, end] pair of "
+                         "the trans pipelines), masks [0,1,0,1], spatial + temporal joint branch (not the headline workload)")
     ap.add_argument("--controlnet", action="store_true",
                     help="also run the ControlNet-SVD encoder every step (SURVEY.md 8f rank 1; not the headline workload)")
     return ap.parse_args()
@@ -159,6 +162,25 @@ def main():
         dom = torch.randn(1, 1, 1000, generator=torch.Generator().manual_seed(12348)).half().to(dev)
         flow = torch.randn(1, 1, 1000, generator=torch.Generator().manual_seed(12349)).half().to(dev)
     lat0, img, emb, ids = synthetic_inputs(dev, args.frames, h, w)
+    nclips = 1
+    if args.joint:
+        if distributed:
+            raise SystemExit("--joint is a single-GPU option")
+        from lkgd_amd import patch
+        patch.apply_patch(pipe, with_temporal_block=True)
+        patch.initialize_joint_layers(pipe)
+        with torch.no_grad():                      # zero-init joint layers would be an identity branch: give them weights
+            g = torch.Generator().manual_seed(12350)
+            for name, prm in unet.named_parameters():
+                if "attn1n" in name or "conv1n" in name:
+                    prm.copy_((torch.randn(prm.shape, generator=g) * (0.5 / max(prm.shape[-1], 1) ** 0.5)).to(prm))
+        unet.invalidate()
+        patch.set_joint_attention_mask(pipe, [0, 1, 0, 1])
+        nclips = 2
+        lat0 = torch.cat([lat0, 0.9 * lat0.flip(1)])
+        img = torch.stack([img[0], img[0], img[1], 0.8 * img[1]])        # [u1, u2, c1, c2]
+        emb = torch.stack([emb[0], emb[0], emb[1], 0.8 * emb[1]])
+        ids = ids[:1].repeat(4, 1)
     ctrl_cond = None
     if args.controlnet:
         if distributed:
@@ -234,7 +256,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args)
-        fps = args.steps * args.frames / dt
+        fps = args.steps * nclips * args.frames / dt
         line = {
             "metric": "denoised frames/sec (14f x 576x1024, 25-step Euler)", "value": round(fps, 4),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -245,6 +267,7 @@ def main():
                                    + ("ControlNet pipeline loop (pipeline_stable_video_diffusion_controlnet, NOT the headline)"
                                       if args.controlnet else
                                       "LKGD UNet with domain / flow features (configs[2], NOT the headline)" if args.lk else
+                                      "TWO clips with the patch joint-attention hooks, masks [0,1,0,1] (NOT the headline)" if args.joint else
                                       "vanilla pipeline_stable_video_diffusion_trans loop (configs[1])")
                                    + (" [TINY UNET - INVALID]" if args.tiny else ""),
                        "unet": "random-init SVD shapes (320,640,1280,1280), heads (5,10,20,20), 1.52 B params",
