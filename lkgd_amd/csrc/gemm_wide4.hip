@@ -71,11 +71,13 @@ __device__ __forceinline__ void wide4_ktile_a(int xa0, int xa1, int wa0, int wa1
 // statement B: K-step 1 (80 MFMAs) and the ten weight-row loads.  Between A and B the C++ advances the A-row sources to the
 // K-tile after next (next_a) while K-step 0's MFMAs drain; the weight sources advance after B (next_w: scalar but for a
 // tile change).
-__device__ __forceinline__ void wide4_ktile_b(int wa1, const WideIn& in, int m_a) {
+// (WIDE4_TAIL: wa0n / xa0n = fragment-0 addresses of the OTHER stage: the statement ends with the K-tile boundary - vmcnt
+// wait, barrier, the next K-tile's first reads - in front of its last eight MFMAs)
+__device__ __forceinline__ void wide4_ktile_b(int wa1, const WideIn& in, int m_a, int wa0n, int xa0n) {
   asm volatile(WIDE4_KTILE_ASM_B
                :
                : "v"(wa1), "v"(in.oB[0]), "v"(in.oB[1]), "v"(in.oB[2]), "v"(in.oB[3]), "v"(in.oB[4]), "v"(in.oB[5]),
-                 "v"(in.oB[6]), "v"(in.oB[7]), "v"(in.oB[8]), "v"(in.oB[9]), "s"(in.wk), "s"(m_a)
+                 "v"(in.oB[6]), "v"(in.oB[7]), "v"(in.oB[8]), "v"(in.oB[9]), "s"(in.wk), "s"(m_a), "v"(wa0n), "v"(xa0n)
                : "memory", "scc", WIDE4_CLOBBERS);
 }
 
@@ -230,21 +232,30 @@ __global__ __launch_bounds__(WNT, 1) __attribute__((amdgpu_num_vgpr(WIDE4_VC))) 
   next_a();                     // K-tile 1
   next_w(in);
 
+#if WIDE4_TAIL
+  asm volatile(WIDE4_KTILE_ASM_PRO : : "v"(xa0), "v"(wa0) : "memory", WIDE4_CLOBBERS);   // K-tile 0 landed, first reads out
+#endif
   int cur = 0, kt = 0, tile = tile_begin;
   bool skip_wait = false;
 #pragma unroll 1
   for (int s = 0; s < total; ++s) {
     // K-tile s must have landed (it is the only LDS-DMA batch in flight at this point); the K-tile body starts with the
     // workgroup barrier, issues K-tile s+1's loads into the other stage and computes K-tile s
+#if !WIDE4_TAIL
     if (!skip_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     skip_wait = false;
+    (void)skip_wait;
     const int m_a = (cur ^ 1) * WSTAGE_BYTES + w * 1024;
     if (kt == 0) wide4_ktile_a<true>(xa0, xa1, wa0, wa1, ag.aptr, m_a);
     else wide4_ktile_a<false>(xa0, xa1, wa0, wa1, ag.aptr, m_a);
 #ifndef WIDE_X_NONEXT             /* timing knob: sources never advance (wrong results) */
     next_a();                   // K-tile s+2's A-row sources, while K-step 0's MFMAs drain
 #endif
-    wide4_ktile_b(wa1, in, m_a);
+    {
+      const int d = cur ? -WSTAGE_BYTES : WSTAGE_BYTES;
+      wide4_ktile_b(wa1, in, m_a, wa0 + d, xa0 + d);
+    }
 #ifndef WIDE_X_NONEXT
     next_w(in);                 // ... and its weight-row sources
 #endif

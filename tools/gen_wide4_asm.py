@@ -54,6 +54,13 @@ def wreg(g):
     return "v[%d:%d]" % (b, b + 3)
 
 
+# 1: the K-tile boundary (vmcnt wait, workgroup barrier, the first nine fragment reads of the next K-tile) sits in front of the
+# LAST weight-fragment step's eight MFMAs instead of between two K-tiles: with one wave per SIMD nothing else covers the
+# barrier skew and the first reads' latency.  Statement B then takes %13 wa0 / %14 xa0 of the OTHER stage; a one-off prologue
+# statement (WIDE4_KTILE_ASM_PRO: %0 xa0, %1 wa0) does the same boundary before the first K-tile.
+TAIL = int(os.environ.get("WIDE4_TAIL", "0"))      # measured neutral (0.705 vs 0.706-0.713 ms on 32768x2560x5120): off
+
+
 class Q:
     """in-order LDS read queue: lgkmcnt(N) guarantees everything but the N youngest reads has returned"""
 
@@ -75,11 +82,16 @@ def body(first, part):
     lines = []
     qq = Q(lines)
     if part == 0:
-        lines += ["WIDE4_WAIT_TOP", "WIDE4_BAR(" + q("s_barrier") + ")"]
-        # first operands first: MFMA (0,0) can start after two reads
-        qq.read(("w", 0), "ds_read_b128 %s, %%2" % wreg(0))
-        for j in range(8):
-            qq.read(("xa", j), "ds_read_b128 %s, %%0 offset:%d" % (xa(j), j * 2048))
+        if TAIL:
+            lines += ["WIDE4_WAIT_TOP"]             # also retires the reads the previous statement's tail issued
+            qq.issued = [("w", 0)] + [("xa", j) for j in range(8)]
+            qq.done = len(qq.issued)
+        else:
+            lines += ["WIDE4_WAIT_TOP", "WIDE4_BAR(" + q("s_barrier") + ")"]
+            # first operands first: MFMA (0,0) can start after two reads
+            qq.read(("w", 0), "ds_read_b128 %s, %%2" % wreg(0))
+            for j in range(8):
+                qq.read(("xa", j), "ds_read_b128 %s, %%0 offset:%d" % (xa(j), j * 2048))
         qq.read(("w", 1), "ds_read_b128 %s, %%2 offset:2048" % wreg(1))
         stage = []
         for n in range(8):
@@ -107,8 +119,17 @@ def body(first, part):
             g = 10 + i
             if i + 2 < 10:
                 qq.read(("w", g + 2), "ds_read_b128 %s, %%0 offset:%d" % (wreg(g + 2), (i + 2) * 2048))
-            m0 = q("s_add_u32 m0, %12, 32768") if i == 0 else q("s_add_u32 m0, m0, 4096")
-            lines.append(m0 + " " + q("s_nop 0") + " WIDE4_LD(" + q("global_load_lds_dwordx4 %%%d, %%11" % (1 + i)) + ")")
+            loads = ([0, 1] if i == 0 else [i + 1] if i < 9 else []) if TAIL else [i]
+            for n in loads:
+                m0 = q("s_add_u32 m0, %12, 32768") if n == 0 else q("s_add_u32 m0, m0, 4096")
+                lines.append(m0 + " " + q("s_nop 0") + " WIDE4_LD(" + q("global_load_lds_dwordx4 %%%d, %%11" % (1 + n)) + ")")
+            if TAIL and i == 9:
+                qq.need(("w", g))
+                lines.append(q("s_waitcnt vmcnt(0)"))
+                lines.append("WIDE4_BAR(" + q("s_barrier") + ")")
+                qq.read(("w0n",), "ds_read_b128 %s, %%13" % wreg(0))
+                for j in range(8):
+                    qq.read(("xan", j), "ds_read_b128 %s, %%14 offset:%d" % (xa(j), j * 2048))
             for j in range(8):
                 qq.need(("w", g), ("xb", j))
                 lines.append("WIDE4_MM(" + q("v_mfma_f32_16x16x32_f16 %s, %s, %s, %s" % (acc(i, j), wreg(g), xb(j), acc(i, j))) + ")")
@@ -121,6 +142,10 @@ with open(out, "w") as f:
     f.write("#define WIDE4_KTILE_ASM_FIRST_A \\\n  " + body(True, 0) + "\n\n")
     f.write("#define WIDE4_KTILE_ASM_NEXT_A \\\n  " + body(False, 0) + "\n\n")
     f.write("#define WIDE4_KTILE_ASM_B \\\n  " + body(False, 1) + "\n\n")
+    pro = [q("s_waitcnt vmcnt(0)"), q("s_barrier"), q("ds_read_b128 %s, %%1" % wreg(0))] + \
+          [q("ds_read_b128 %s, %%0 offset:%d" % (xa(j), j * 2048)) for j in range(8)]
+    f.write("#define WIDE4_KTILE_ASM_PRO \\\n  " + " \\\n  ".join(pro) + "\n\n")
+    f.write("#define WIDE4_TAIL %d\n" % TAIL)
     f.write("#define WIDE4_VC %d\n" % VC)
     f.write("#define WIDE4_CLOBBERS " + ", ".join('"a%d"' % i for i in range(256)) + ", " +
             ", ".join('"v%d"' % i for i in range(VC, 256)) + "\n")
