@@ -382,9 +382,9 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     pick = 4;                                            // every N = 320 / 640 / 960 / 1280 / 1920 / 3840 shape of the model
                                                          // whose 256x320 tiles fill at least half the CUs (also the 8064-row
                                                          // 18x32 level of a CFG-parallel rank: 0.284 vs 0.334 ms on its 3x3 conv)
-  } else if (d->M < 8192) {
-    // the 9x16 level (M = 4032): 256-row tilings leave most CUs idle; 128x128 at two workgroups per CU fills best,
-    // except for the wide-N projections (QKV: 16 x 12 tiles of 256x320)
+  } else if (d->M < 12288) {
+    // the 9x16 level (M = 4032; also the 9216-row 36x64 level of a rank of 8): 256-row tilings leave most CUs idle; 128x128
+    // at two workgroups per CU fills best, except for the wide-N projections (QKV: 16 x 12 tiles of 256x320)
     pick = (wide_ok && plain && d->geglu == 0 && d->N % 320 == 0 && d->N >= 2560 && d->M > 256 && !d->res1) ? 4 : 1;
   } else {
     pick = 3;

@@ -126,7 +126,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     d.ldc = _ld(out)
     d.s_acc, d.r1, d.r2 = s_acc, r1, r2
     d.geglu = int(geglu)        # 0 off, 32 / 80 = interleave width the weights were packed with
-    if M < 8192:                # few-row problems may cut K into slices (lkgd_hip.h: lkgd_gemm_desc.workspace)
+    if M < 12288:               # few-row problems may cut K into slices (lkgd_hip.h: lkgd_gemm_desc.workspace)
         ws = splitk_workspace(out.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     ev = GEMM_EVENTS

@@ -12,7 +12,7 @@ t0 = time.time()
 while time.time() - t0 < 2.0:
     for _ in range(20): a0 @ a0
     torch.cuda.synchronize()
-for M, H, W in ((8064, 18, 32), (32256, 36, 64), (4032, 18, 32), (16128, 36, 64)):
+for M, H, W in [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or ((8064, 18, 32), (32256, 36, 64), (4032, 18, 32), (16128, 36, 64)):
     C = 1280 if H == 18 else 640
     x = torch.randn(M, C, device=DEV, dtype=torch.float16) * 0.1
     cases = {}
