@@ -317,7 +317,7 @@ static int check_desc(const lkgd_gemm_desc* d) {
 }
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
-extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_wide.hip
+extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit);   // gemm_wide.hip
 extern "C" int lkgd_gemm_wide4_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);    // gemm_wide4.hip
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
 extern "C" int lkgd_gemm_pp_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);       // gemm_pp.hip
@@ -328,7 +328,25 @@ extern "C" int lkgd_gemm_pp_launch(const lkgd_gemm_desc* d, hipStream_t stream, 
 // 6 = force the 256x256 ping-pong kernel where it applies
 static int gemm_variant_override = 0;
 extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = v; }
+extern "C" void lkgd_debug_set_gemm_splitk(int on);
+
+// Split-K for the 256x320 kernel on few-row problems (< half the CUs get a tile): the smallest number of EQUAL K slices
+// (a divisor of K / 64 up to 8, slices of >= 16 K-tiles, partials within the caller's workspace) whose virtual tiles fill
+// >= 75 % of the CU rounds they occupy; 0 = none.  Measured (tools/micro/m8064.py): 4032 x 1280 3x3 conv 0.150 -> 0.115 ms,
+// FF-out (K = 5120) 0.084 -> 0.070; 2304 x 1280 conv 0.102 -> 0.092; thinner slices or fuller machines lose to 128x128 tiles.
 static bool gemm_splitk_enabled = true;
+static int wide_split(const lkgd_gemm_desc* d, long long tiles_wide, int cus) {
+  if (!gemm_splitk_enabled || d->geglu || !d->workspace || !aligned16(d->workspace) || tiles_wide * 2 >= cus) return 0;
+  const int nk = d->K / BK;
+  for (int c = 2; c <= 8 && c * 16 <= nk; ++c) {
+    if (nk % c) continue;
+    if ((long long)c * d->M * d->N * 4 > d->workspace_bytes) return 0;
+    const long long vt = tiles_wide * c, rounds = (vt + cus - 1) / cus;
+    if (vt * 4 >= rounds * cus * 3) return c;
+  }
+  return 0;
+}
+
 extern "C" void lkgd_debug_set_gemm_splitk(int on) { gemm_splitk_enabled = on != 0; }
 
 extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
@@ -369,6 +387,7 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   const bool stream_ok = rows16 && d->geglu != 80;
   const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
   int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide, 5 = rowpanel, 6 = ping-pong
+  int wide_ks = 1;
   if (d->geglu == 80) {
     if (!wide_ok) return LKGD_E_SHAPE;
     pick = v == 7 ? 7 : 4;                                            // 80-wide GEGLU interleave exists only in the 256x320 kernel
@@ -382,10 +401,13 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     pick = 4;                                            // every N = 320 / 640 / 960 / 1280 / 1920 / 3840 shape of the model
                                                          // whose 256x320 tiles fill at least half the CUs (also the 8064-row
                                                          // 18x32 level of a CFG-parallel rank: 0.284 vs 0.334 ms on its 3x3 conv)
+  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->M >= 2048 && (wide_ks = wide_split(d, tiles_wide, cus)) >= 2) {
+    pick = 4;                                            // few rows, deep K: 256x320 tiles over equal K slices
   } else if (d->M < 12288) {
+    wide_ks = 1;
     // the 9x16 level (M = 4032; also the 9216-row 36x64 level of a rank of 8): 256-row tilings leave most CUs idle; 128x128
     // at two workgroups per CU fills best, except for the wide-N projections (QKV: 16 x 12 tiles of 256x320)
-    pick = (wide_ok && plain && d->geglu == 0 && d->N % 320 == 0 && d->N >= 2560 && d->M > 256 && !d->res1) ? 4 : 1;
+    pick = (wide_ok && plain && d->geglu == 0 && d->N % 320 == 0 && d->N >= 2560 && d->M >= 2048 && !d->res1) ? 4 : 1;
   } else {
     pick = 3;
   }
@@ -397,7 +419,17 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   if (d->geglu == 80 && pick != 4 && pick != 7) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the 256x320 kernels
   if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
   if (pick == 6) return lkgd_gemm_pp_launch(d, (hipStream_t)stream, cus);
-  if (pick == 4) return lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus);
+  if (pick == 4) {
+    if (v == 4) wide_ks = wide_split(d, tiles_wide, cus);      // forced variant: same slicing rule
+    const int ks = wide_ks >= 2 ? wide_ks : 1;
+    rc = lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus, ks);
+    if (rc != LKGD_OK || ks == 1) return rc;
+    const int tn128 = (d->N + BN - 1) / BN;
+    const unsigned rblocks = (unsigned)(((d->M + 31) / 32) * tn128);
+    hipLaunchKernelGGL(lkgd_gemm_splitk_reduce, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *d, tn128, ks,
+                       (const float*)d->workspace);
+    return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+  }
   if (pick == 7) return lkgd_gemm_wide4_launch(d, (hipStream_t)stream, cus);
   if (pick == 3) return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
   int tiles_n = (d->N + BN - 1) / BN;

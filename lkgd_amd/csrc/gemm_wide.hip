@@ -114,7 +114,7 @@ __device__ __forceinline__ float4_t wide_read_acc() {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit, float* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -123,7 +123,10 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
   const int l15 = lane & 15, lq = lane >> 4;
 
   // ---- XCD-cooperative persistent schedule (see gemm_stream.hip)
-  const int ntiles = tiles_m * tiles_n;
+  // split-K (few-row problems, ksplit > 1): the stream runs over VIRTUAL tiles vt = tile * ksplit + slice; a slice owns
+  // K-tiles [slice * nk, (slice + 1) * nk) (equal slices: the launcher picks a divisor) and leaves its fp32 partial tile in
+  // ws[slice][M][N] for lkgd_gemm_splitk_reduce.  Slices of a tile are adjacent in the stream: same XCD, shared panels.
+  const int ntiles = tiles_m * tiles_n * ksplit;
   const int G = gridDim.x;
   const int xcd = blockIdx.x & 7, c = blockIdx.x >> 3;
   const int nc = (G - xcd + 7) >> 3;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
   const int xe = xb + q8 + (xcd < r8 ? 1 : 0);
   const int my_tiles = (xe - xb - c + nc - 1) / nc;
   const int tile_begin = xb + c;
-  const int nk = p.K / BK;
+  const int nk = p.K / BK / ksplit;
   const int total = (my_tiles > 0 ? my_tiles : 0) * nk;
   if (total <= 0) return;
 #ifdef WIDE_X_STAGGER
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
   float rcp0, rcp1;
   lean_rcps<MODE>(p, rcp0, rcp1);
   int st_tile = tile_begin - nc, st_kt = nk - 1, st_s = -1, st_par = 0, ep_par = 0;
+  int st_k0 = 0;                // first K-tile of the staged virtual tile's slice
   ag.seg_k0 = 0; ag.seg_end = 0; ag.zmask = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { ag.rd[i].base = -1; ag.rd[i].yx = 0; ag.aptr[i] = (const half_t*)p.zeros; }
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
         st_kt = 0;
         st_tile += nc;
         int tm, tn;
-        supertile<4>(st_tile, tiles_m, tiles_n, tm, tn);
+        supertile<4>(st_tile / ksplit, tiles_m, tiles_n, tm, tn);
+        st_k0 = (st_tile % ksplit) * nk;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ag.rd[i] = lean_row<MODE>(p, tm * WBM + srow + 64 * i, rcp0, rcp1);
 #pragma unroll
@@ -202,15 +207,20 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
           __builtin_amdgcn_global_load_lds(GLB_PTR(rb + (long long)i1 * p.ldrb + col), LDS_PTR(dst + WRB_STRIP), 4, 0, 0);
         }
       }
-      if (st_kt * BK >= ag.seg_end) {
-        lean_segment<MODE, 4>(p, ag, st_kt * BK, schunk);       // aptr = the rows' sources at the segment's first K-tile
+      if ((st_k0 + st_kt) * BK >= ag.seg_end) {
+        lean_segment<MODE, 4>(p, ag, (st_k0 + st_kt) * BK, schunk);   // aptr = the rows' sources at the segment's first K-tile
+        const int into = (st_k0 + st_kt) * BK - ag.seg_k0;             // a K slice may start inside a segment
+        if (into) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ag.aptr[i] += ((ag.zmask >> i) & 1u) ? 0 : into;
+        }
       } else {
         // within a segment a row's source advances by one K-tile (128 bytes); zero-page rows stay
 #pragma unroll
         for (int i = 0; i < 4; ++i) ag.aptr[i] += ((ag.zmask >> i) & 1u) ? 0 : BK;
       }
     }
-    in.wk = wbase + st_kt * BK;
+    in.wk = wbase + (st_k0 + st_kt) * BK;
   };
 
   // fragment rows: tokens wr*64 + mi*16 + l15, weights wc*160 + ni*16 + l15.  The swizzle key (row>>1)&7 is the same
@@ -264,7 +274,8 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
       skip_wait = true;
       kt = 0;
       int tm, tn;
-      supertile<4>(tile, tiles_m, tiles_n, tm, tn);
+      supertile<4>(tile / ksplit, tiles_m, tiles_n, tm, tn);
+      const int slice = tile % ksplit;
       tile += nc;
       const int m0 = tm * WBM + wr * 64 + l15;
       const int n0 = tn * WBN + wc * 160 + 4 * lq;
@@ -281,6 +292,13 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
       auto epi = [&](int j, const float4_t (&e)[10]) {
         const long long m = m0 + j * 16;
         if (m >= p.M) return;
+        if (ksplit > 1) {            // fp32 partial tile of this K slice; bias / residuals / rounding happen in the reduce pass
+          float* dst = ws + ((long long)slice * p.M + m) * p.N;
+#pragma unroll
+          for (int i = 0; i < 10; ++i)
+            if (n0 + i * 16 < p.N) *(float4_t*)(dst + n0 + i * 16) = e[i];
+          return;
+        }
         if (MODE != LKGD_A_PLAIN || !p.geglu) {
           unsigned idx = 0;          // 32-bit row-map arithmetic: M < 2^24 is a launch condition of this kernel
           if (rbp && !rb_lds) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) +
@@ -348,7 +366,8 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's trailing loads must land before the LDS is released
 }
 
-extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus) {
+// ksplit > 1: K is cut into ksplit equal slices (ksplit divides K / 64); the caller runs lkgd_gemm_splitk_reduce afterwards
+extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -361,16 +380,18 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
     attr_set = true;
   }
   int tiles_m = (d->M + WBM - 1) / WBM, tiles_n = (d->N + WBN - 1) / WBN;
-  long long ntiles = (long long)tiles_m * tiles_n;
+  if (ksplit < 1 || (d->K / BK) % ksplit || (ksplit > 1 && (!d->workspace || d->geglu))) return LKGD_E_SHAPE;
+  long long ntiles = (long long)tiles_m * tiles_n * ksplit;
   if (ntiles > 0x7fffffffLL) return LKGD_E_SHAPE;
   int grid = ntiles < cus ? (int)ntiles : cus;
   if (d->M >= (1 << 24)) return LKGD_E_SHAPE;            // float-reciprocal row decomposition (gemm_common.h)
+  float* ws = (float*)d->workspace;
   if (d->mode == LKGD_A_PLAIN)
-    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws);
   else if (d->mode == LKGD_A_CONV3X3)
-    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws);
   else if (d->mode == LKGD_A_TCONV3)
-    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws);
   else
     return LKGD_E_MODE;
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;

@@ -42,7 +42,7 @@ def zeros_page(device) -> torch.Tensor:
 
 
 _splitk_ws = {}
-SPLITK_WORKSPACE_BYTES = 64 << 20
+SPLITK_WORKSPACE_BYTES = 256 << 20
 
 
 def splitk_workspace(device) -> torch.Tensor:

@@ -494,3 +494,46 @@ def test_gemm_split_k_few_rows():
     out = torch.empty(M, 256, dtype=torch.float16, device=DEV)
     ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=512, K=C, bias=bp.to(DEV), geglu=half)
     _close(out, hid * F.gelu(gate), what="split-K geglu")
+
+
+def test_gemm_split_k_on_256x320_tiles():
+    """few-row, deep-K problems on the 256x320 kernel: equal K slices as virtual tiles + the shared reduce pass (the 18x32 /
+    9x16 levels of the model at 4032 / 2304 rows).  Same result as the unsplit kernel up to fp32 summation order; a slice may
+    start in the middle of a (tap, source) segment of the implicit convolution."""
+    from lkgd_amd import _lib, ops
+    from lkgd_amd.packing import pack_conv3x3
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(23)
+    # plain: 12288 x 640 x 2048 -> 96 tiles, two slices of 16 K-tiles
+    M, N, K = 12288, 640, 2048
+    a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g)
+    res = _h(torch.randn(M, N, generator=g))
+    rows = torch.arange(0, M, 53)
+    ref = a[rows].float() @ w.float().T + b + 0.5 * res[rows].float()
+    outs = []
+    for on in (1, 0):
+        L.lkgd_debug_set_gemm_splitk(on)
+        out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=b.to(DEV), res1=res.to(DEV), r1=0.5)
+        outs.append(out.cpu())
+    L.lkgd_debug_set_gemm_splitk(1)
+    _close(outs[0][rows], ref, what="256x320 split-K plain")
+    assert (outs[0].float() - outs[1].float()).abs().max().item() <= 4e-3 * ref.abs().max().item()
+    # 3x3 conv, two sources (the slice boundary falls inside a tap): 3 images of 64x64, 128 + 128 channels -> K = 2304
+    Nimg, C0, C1, Cout, H, W = 3, 128, 128, 320, 64, 64
+    x0, x1 = _h(torch.randn(Nimg, C0, H, W, generator=g)), _h(torch.randn(Nimg, C1, H, W, generator=g))
+    wc = _h(torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 48)
+    bc = torch.randn(Cout, generator=g)
+    refc = F.conv2d(torch.cat([x0, x1], 1).float(), wc.float(), bc, padding=1)
+    outs = []
+    for on in (1, 0):
+        L.lkgd_debug_set_gemm_splitk(on)
+        out = torch.empty(Nimg * H * W, Cout, dtype=torch.float16, device=DEV)
+        ops.gemm(_tokens(x0).to(DEV), pack_conv3x3(wc).to(DEV), out, M=Nimg * H * W, N=Cout, K=9 * (C0 + C1),
+                 a1=_tokens(x1).to(DEV), csplit=C0, bias=bc.to(DEV), mode=ops.A_CONV3X3, Cin=C0 + C1,
+                 conv=(H, W, H, W, 1, 0))
+        outs.append(out.cpu())
+    L.lkgd_debug_set_gemm_splitk(1)
+    _close(_untokens(outs[0], Nimg, H, W), refc, what="256x320 split-K conv3x3")
+    assert (outs[0].float() - outs[1].float()).abs().max().item() <= 4e-3 * refc.abs().max().item()
