@@ -113,8 +113,11 @@ __device__ __forceinline__ float4_t wide_read_acc() {
   return (float4_t){a, b, c, d};
 }
 
-template <int MODE>
-__global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit, float* ws) {
+// SPLIT = false is the production instantiation: ksplit folds to 1 and the slice bookkeeping disappears (with it in, the
+// allocator spilled 19-34 instead of 2-20 registers around the K-loop and every launch of this kernel got ~2 % slower)
+template <int MODE, bool SPLIT>
+__global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit_arg, float* ws) {
+  const int ksplit = SPLIT ? ksplit_arg : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
       auto epi = [&](int j, const float4_t (&e)[10]) {
         const long long m = m0 + j * 16;
         if (m >= p.M) return;
-        if (ksplit > 1) {            // fp32 partial tile of this K slice; bias / residuals / rounding happen in the reduce pass
+        if (SPLIT) {                 // fp32 partial tile of this K slice; bias / residuals / rounding happen in the reduce pass
           float* dst = ws + ((long long)slice * p.M + m) * p.N;
 #pragma unroll
           for (int i = 0; i < 10; ++i)
@@ -370,13 +373,11 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            WLDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            WLDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) !=
-        hipSuccess)
-      return LKGD_E_LAUNCH;
+    const void* fns[6] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, false>,
+                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>,
+                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, true>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, true>};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) != hipSuccess) return LKGD_E_LAUNCH;
     attr_set = true;
   }
   int tiles_m = (d->M + WBM - 1) / WBM, tiles_n = (d->N + WBN - 1) / WBN;
@@ -386,12 +387,17 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
   int grid = ntiles < cus ? (int)ntiles : cus;
   if (d->M >= (1 << 24)) return LKGD_E_SHAPE;            // float-reciprocal row decomposition (gemm_common.h)
   float* ws = (float*)d->workspace;
-  if (d->mode == LKGD_A_PLAIN)
-    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws);
-  else if (d->mode == LKGD_A_CONV3X3)
-    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws);
-  else if (d->mode == LKGD_A_TCONV3)
-    hipLaunchKernelGGL(lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws);
+#define WIDE_LAUNCH(MODE_)                                                                                              \
+  {                                                                                                                     \
+    if (ksplit > 1)                                                                                                     \
+      hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws); \
+    else                                                                                                                \
+      hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, false>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, 1, ws);     \
+  }
+  if (d->mode == LKGD_A_PLAIN) WIDE_LAUNCH(LKGD_A_PLAIN)
+  else if (d->mode == LKGD_A_CONV3X3) WIDE_LAUNCH(LKGD_A_CONV3X3)
+  else if (d->mode == LKGD_A_TCONV3) WIDE_LAUNCH(LKGD_A_TCONV3)
+#undef WIDE_LAUNCH
   else
     return LKGD_E_MODE;
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
