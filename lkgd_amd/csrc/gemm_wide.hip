@@ -116,7 +116,7 @@ __device__ __forceinline__ float4_t wide_read_acc() {
 // SPLIT = false is the production instantiation: ksplit folds to 1 and the slice bookkeeping disappears (with it in, the
 // allocator spilled 19-34 instead of 2-20 registers around the K-loop and every launch of this kernel got ~2 % slower)
 template <int MODE, bool SPLIT>
-__global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit_arg, float* ws) {
+__device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, int tiles_n, int ksplit_arg, float* ws) {
   const int ksplit = SPLIT ? ksplit_arg : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
         st_tile += nc;
         int tm, tn;
         supertile<4>(st_tile / ksplit, tiles_m, tiles_n, tm, tn);
-        st_k0 = (st_tile % ksplit) * nk;
+        st_k0 = SPLIT ? (st_tile % ksplit) * nk : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ag.rd[i] = lean_row<MODE>(p, tm * WBM + srow + 64 * i, rcp0, rcp1);
 #pragma unroll
@@ -212,8 +212,8 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
       }
       if ((st_k0 + st_kt) * BK >= ag.seg_end) {
         lean_segment<MODE, 4>(p, ag, (st_k0 + st_kt) * BK, schunk);   // aptr = the rows' sources at the segment's first K-tile
-        const int into = (st_k0 + st_kt) * BK - ag.seg_k0;             // a K slice may start inside a segment
-        if (into) {
+        const int into = SPLIT ? (st_k0 + st_kt) * BK - ag.seg_k0 : 0;   // a K slice may start inside a segment
+        if (SPLIT && into) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) ag.aptr[i] += ((ag.zmask >> i) & 1u) ? 0 : into;
         }
@@ -369,13 +369,22 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's trailing loads must land before the LDS is released
 }
 
+template <int MODE>
+__global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n) {
+  wide_body<MODE, false>(p, tiles_m, tiles_n, 1, nullptr);
+}
+template <int MODE>
+__global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_split_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit, float* ws) {
+  wide_body<MODE, true>(p, tiles_m, tiles_n, ksplit, ws);
+}
+
 // ksplit > 1: K is cut into ksplit equal slices (ksplit divides K / 64); the caller runs lkgd_gemm_splitk_reduce afterwards
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[6] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, false>,
-                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>,
-                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, true>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, true>};
+    const void* fns[6] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>,
+                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>,
+                          (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) != hipSuccess) return LKGD_E_LAUNCH;
     attr_set = true;
@@ -390,9 +399,9 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
 #define WIDE_LAUNCH(MODE_)                                                                                              \
   {                                                                                                                     \
     if (ksplit > 1)                                                                                                     \
-      hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws); \
+      hipLaunchKernelGGL(lkgd_gemm_wide_split_kernel<MODE_>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws); \
     else                                                                                                                \
-      hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, false>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, 1, ws);     \
+      hipLaunchKernelGGL(lkgd_gemm_wide_kernel<MODE_>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);     \
   }
   if (d->mode == LKGD_A_PLAIN) WIDE_LAUNCH(LKGD_A_PLAIN)
   else if (d->mode == LKGD_A_CONV3X3) WIDE_LAUNCH(LKGD_A_CONV3X3)
