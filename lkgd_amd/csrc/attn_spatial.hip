@@ -1,6 +1,7 @@
 // Spatial self-attention, head_dim 64, fp16 in / fp32 softmax+accumulate (include/lkgd_hip.h section 4).
 //
-// Flash-style for gfx950: one 256-thread workgroup = 4 waves x 32 query rows; K/V tiles of 64 keys stream through an
+// Flash-style for gfx950: one workgroup = NW waves x 32 query rows (NW = 4, 8 or 16 by sequence length: a staged K/V tile
+// serves 32*NW queries); K/V tiles of 64 keys stream through an
 // LDS ring filled by LDS-DMA (global_load_lds_dwordx4, the XOR swizzles applied on the source side, no staging
 // registers: 120 VGPRs, four waves per SIMD): the next tile is issued right after the barrier that opens a tile; one
 // barrier per tile.  Measured on this kernel (tools/micro/attn_pmc.sh, attn_lib.py): VALU issue 62 % and MFMA 35 % of
@@ -16,7 +17,6 @@
 // Softmax scale and log2(e) are folded into one FMA feeding v_exp_f32 (exp2).
 #include "common.h"
 
-#define QBLK 128
 #define KVBLK 64
 #ifndef ATT_NST
 #define ATT_NST 2   // 2 stages (32 KiB) keep four workgroups per CU; a third stage measured 4 % slower (occupancy 3)
@@ -26,7 +26,10 @@
 __device__ __forceinline__ int k_lds_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_lds_off(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4); }
 
-__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __restrict__ q, int ldq,
+// NW = waves per workgroup (32 query rows each): a K/V tile staged once serves 32*NW queries, so NW = 8 halves the
+// L2 -> LDS traffic per flop of NW = 4 (11 instead of 22 bytes per clock and CU at S = 9216)
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel(const half_t* __restrict__ q, int ldq,
                                                               const half_t* __restrict__ k, int ldk,
                                                               const half_t* __restrict__ v, int ldv,
                                                               half_t* __restrict__ out, int ldo, int S, int heads,
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
   const int kvn = kvmap ? kvmap[n] : n;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[qrow][16*ks + 8*h + 0..7]
+  constexpr int QBLK = NW * 32;
   const int qrow = qb * QBLK + w * 32 + l31;
   const int qrow_c = qrow < S ? qrow : S - 1;
   const half_t* qp = q + ((long long)n * S + qrow_c) * ldq + head * 64 + h * 8;
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
   const half_t* kbase = k + (long long)kvn * S * ldk + head * 64;
   const half_t* vbase = v + (long long)kvn * S * ldv + head * 64;
   const int srow0 = t >> 3, sc = t & 7;
+  // (NW = 8: 512 threads cover the 64 rows of a tile in one pass; NW = 4: rows srow0 and srow0 + 32)
   const int kc0 = (sc ^ ((srow0 >> 1) & 7)) * 8, kc1 = (sc ^ (((srow0 + 32) >> 1) & 7)) * 8;
   const int vc0 = (sc ^ (((srow0 >> 1) & 1) << 2)) * 8, vc1 = (sc ^ ((((srow0 + 32) >> 1) & 1) << 2)) * 8;
 #define ISSUE_TILE(tile, st)                                                   \
@@ -69,10 +74,10 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
     if (key0_ >= S) key0_ = S - 1; /* clamped rows are masked in the scores */ \
     if (key1_ >= S) key1_ = S - 1;                                             \
     char* kb_ = smem + (st) * (2 * KVBLK * 128) + w * 1024;                    \
-    glds16(kbase + (long long)key0_ * ldk + kc0, kb_);                         \
-    glds16(kbase + (long long)key1_ * ldk + kc1, kb_ + 32 * 128);              \
-    glds16(vbase + (long long)key0_ * ldv + vc0, kb_ + KVBLK * 128);           \
-    glds16(vbase + (long long)key1_ * ldv + vc1, kb_ + KVBLK * 128 + 32 * 128); \
+    if (NW <= 8 || w < 8) glds16(kbase + (long long)key0_ * ldk + kc0, kb_);   \
+    if (NW == 4) glds16(kbase + (long long)key1_ * ldk + kc1, kb_ + 32 * 128); \
+    if (NW <= 8 || w < 8) glds16(vbase + (long long)key0_ * ldv + vc0, kb_ + KVBLK * 128); \
+    if (NW == 4) glds16(vbase + (long long)key1_ * ldv + vc1, kb_ + KVBLK * 128 + 32 * 128); \
   }
 
   float16_t oacc[2];
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
   for (int j = 0; j < ntiles; ++j) {
     // tile j has landed (this thread's four loads; the barrier publishes everyone's) - tile j+1 may stay in flight - and
     // every wave is done with tile j-1, whose stage takes tile j+2
-    if (ATT_NST > 2 && j + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (ATT_NST > 2 && j + 1 < ntiles) { if (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (j + ATT_NST - 1 < ntiles) {
@@ -209,6 +214,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const half_t* __re
   }
 }
 
+static int attn_nw_override = 0;     // A/B knob: 4 or 8 waves per workgroup regardless of S
+extern "C" void lkgd_debug_set_attn_waves(int nw) { attn_nw_override = nw; }
+
 extern "C" int lkgd_attn_spatial(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
                                  void* out, int32_t ldo, int32_t nbatch, int32_t S, int32_t heads,
                                  const int32_t* kv_batch_map, float scale, lkgd_stream_t stream) {
@@ -217,11 +225,24 @@ extern "C" int lkgd_attn_spatial(const void* q, int32_t ldq, const void* k, int3
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LKGD_E_ALIGN;
   if (ldq < heads * 64 || ldk < heads * 64 || ldv < heads * 64 || ldo < heads * 64) return LKGD_E_SHAPE;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || ((uintptr_t)out & 7)) return LKGD_E_ALIGN;
+  // queries per workgroup: 512 at S >= 8192, 256 at S >= 2304, else 128 (tools/attn_bench.py with ATTN_WAVES: S = 9216
+  // 4.03 / 3.89 / 3.78 ms for 128 / 256 / 512; S = 2304 0.507 / 0.495 / 0.55; S = 576 0.083 / 0.100: partial last blocks)
+  const int nw = attn_nw_override ? attn_nw_override : (S >= 8192 ? 16 : S >= 2304 ? 8 : 4);
+  const int QBLK = nw * 32;
   int nqb = (S + QBLK - 1) / QBLK;
   long long nwg = (long long)nqb * nbatch * heads;
   if (nwg > 0x7fffffffLL) return LKGD_E_SHAPE;
-  hipLaunchKernelGGL(attn_spatial_kernel, dim3((unsigned)nwg), dim3(256), ATT_LDS, (hipStream_t)stream,
-                     (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, S, heads,
-                     kv_batch_map, scale * 1.4426950408889634f, nqb, (int)nwg);
+  if (nw == 16)
+    hipLaunchKernelGGL(attn_spatial_kernel<16>, dim3((unsigned)nwg), dim3(1024), ATT_LDS, (hipStream_t)stream,
+                       (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, S, heads,
+                       kv_batch_map, scale * 1.4426950408889634f, nqb, (int)nwg);
+  else if (nw == 8)
+    hipLaunchKernelGGL(attn_spatial_kernel<8>, dim3((unsigned)nwg), dim3(512), ATT_LDS, (hipStream_t)stream,
+                       (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, S, heads,
+                       kv_batch_map, scale * 1.4426950408889634f, nqb, (int)nwg);
+  else
+    hipLaunchKernelGGL(attn_spatial_kernel<4>, dim3((unsigned)nwg), dim3(256), ATT_LDS, (hipStream_t)stream,
+                       (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, S, heads,
+                       kv_batch_map, scale * 1.4426950408889634f, nqb, (int)nwg);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }

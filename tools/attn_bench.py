@@ -9,6 +9,9 @@ import torch
 from lkgd_amd import ops
 
 DEV = "cuda:0"
+if os.environ.get("ATTN_WAVES"):        # A/B knob: 4 or 8 waves (128 / 256 queries) per workgroup
+    from lkgd_amd import _lib
+    _lib.lib().lkgd_debug_set_attn_waves(int(os.environ["ATTN_WAVES"]))
 
 
 def bench(fn, iters=5):
