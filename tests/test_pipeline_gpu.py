@@ -420,3 +420,33 @@ def test_controlnet_loop_vs_oracle():
     plain = pipe.denoise((lat0 * float(pipe.scheduler.init_noise_sigma)).half().to(DEV), img.half().to(DEV),
                          enc.half().to(DEV), ids.to(DEV), 2)
     assert _rel(plain, ref) > 1e-3          # the ControlNet branch really changes the result
+
+
+def test_hip_graph_replay_equals_eager_loop():
+    """`pipe.use_hip_graph = True` replays the per-step UNet forward from a captured HIP graph (static input-token and
+    timestep buffers): the very same kernels with the very same arguments, so the latents must be bit-identical - over
+    several steps (the graph is reused) and over a second call (cache hit) and after a weight change (re-capture)."""
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+    _, m = _unet(21)
+    g = torch.Generator().manual_seed(8)
+    lat0 = torch.randn(1, 4, 4, 8, 8, generator=g)
+    enc = torch.cat([torch.zeros(1, 1, 1024), torch.randn(1, 1, 1024, generator=g)]).to(DEV)
+    img = torch.cat([torch.zeros(1, 4, 4, 8, 8), 0.18215 * torch.randn(1, 1, 4, 8, 8, generator=g).repeat(1, 4, 1, 1, 1)])
+    img = img.half().to(DEV)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2).to(DEV)
+    pipe = StableVideoDiffusionPipeline(unet=m)
+
+    def run(steps):
+        pipe.scheduler.set_timesteps(steps)
+        lat = (lat0 * float(pipe.scheduler.init_noise_sigma)).half().to(DEV)
+        return pipe.denoise(lat, img, enc, ids, steps)
+    eager = run(4)
+    pipe.use_hip_graph = True
+    assert torch.equal(run(4), eager)
+    assert torch.equal(run(4), eager)            # second call: cached graph
+    with torch.no_grad():
+        m.conv_out.bias.add_(0.25)
+    m.invalidate()
+    changed = run(4)                             # weights changed -> new packing -> re-capture
+    pipe.use_hip_graph = False
+    assert torch.equal(run(4), changed) and not torch.equal(changed, eager)
