@@ -31,6 +31,21 @@ class StableVideoDiffusionPipelineOutput:
     frames: Union[torch.Tensor, list]
 
 
+def _randn_tensor(shape, generator, device, dtype):
+    """diffusers' `randn_tensor` [EXT utils/torch_utils.py]: a CPU generator serves a GPU target by sampling on the CPU (so
+    seeds reproduce across devices); a list of generators samples per batch entry"""
+    if isinstance(generator, (list, tuple)):
+        if len(generator) == 1:
+            generator = generator[0]
+        else:
+            per = (1,) + tuple(shape[1:])
+            return torch.cat([_randn_tensor(per, g, device, dtype) for g in generator], dim=0)
+    gdev = generator.device if isinstance(generator, torch.Generator) else torch.device(device)
+    if gdev.type != torch.device(device).type and gdev.type == "cpu":
+        return torch.randn(tuple(shape), generator=generator, device="cpu", dtype=dtype).to(device)
+    return torch.randn(tuple(shape), generator=generator, device=device, dtype=dtype)
+
+
 def _append_dims(x, target_dims):
     dims_to_append = target_dims - x.ndim
     if dims_to_append < 0:
@@ -110,8 +125,7 @@ class StableVideoDiffusionPipeline:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
                              f"effective batch size of {batch_size}.")
         if latents is None:
-            gdev = generator.device if isinstance(generator, torch.Generator) else device
-            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+            latents = _randn_tensor(shape, generator, device, dtype)
         else:
             latents = latents.to(device=device, dtype=dtype)
         return ops.scale(latents, float(self.scheduler.init_noise_sigma))
@@ -291,8 +305,8 @@ class StableVideoDiffusionPipeline:
             image_embeddings = self._encode_image(image, device, num_videos_per_prompt, cfg)
         fps = fps - 1
         if image_latents is None:
-            img = self.image_processor.preprocess(image, height=height, width=width).to(device)      # reference :435
-            noise = torch.randn(img.shape, generator=generator, device=img.device, dtype=img.dtype)
+            img = self.image_processor.preprocess(image, height=height, width=width)                 # reference :435
+            noise = _randn_tensor(img.shape, generator, img.device, img.dtype)      # on the image's device, as :449 does
             img = img + noise_aug_strength * noise
             image_latents = self._encode_vae_image(img, device, num_videos_per_prompt, cfg)
         image_latents = image_latents.to(device=device, dtype=torch.float16)

@@ -450,3 +450,60 @@ def test_hip_graph_replay_equals_eager_loop():
     changed = run(4)                             # weights changed -> new packing -> re-capture
     pipe.use_hip_graph = False
     assert torch.equal(run(4), changed) and not torch.equal(changed, eager)
+
+
+class _StandInVAE(torch.nn.Module):
+    """the boundary stand-in the golden generator used (tests/golden/make_goldens.py::_FakeVAE): 8x average pool + fixed
+    channel mix -> 4 latent channels"""
+
+    def __init__(self):
+        super().__init__()
+        from types import SimpleNamespace
+        self.config = SimpleNamespace(block_out_channels=(1, 1, 1, 1), force_upcast=False, scaling_factor=0.18215)
+        self.mix = torch.nn.Parameter(torch.randn(4, 3, generator=torch.Generator().manual_seed(31)))
+
+    @property
+    def dtype(self):
+        return self.mix.dtype
+
+    def encode(self, image):
+        from types import SimpleNamespace
+        z = torch.nn.functional.avg_pool2d(image, 8)
+        z = torch.einsum("oc,bchw->bohw", self.mix.to(z), z) * 0.18215
+        return SimpleNamespace(latent_dist=SimpleNamespace(mode=lambda: z))
+
+
+class _StandInCLIP(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.randn(1024, 3, generator=torch.Generator().manual_seed(32)))
+
+    def forward(self, image):
+        from types import SimpleNamespace
+        return SimpleNamespace(image_embeds=torch.einsum("oc,bc->bo", self.w.to(image), image.mean(dim=(2, 3))))
+
+
+def test_call_from_image_vs_reference_pipeline_golden(golden_dir):
+    """the whole `__call__` from an IMAGE tensor, as the reference was called to make loop.safetensors: CLIP branch,
+    noise augmentation with the caller's generator (seed 42), VAE-encode, CFG duplication, frame repeat, add-time-ids,
+    loop - the boundary wiring is pinned on the embeddings / image latents the reference fed its UNet"""
+    from types import SimpleNamespace
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+    g = load_file(os.path.join(golden_dir, "loop.safetensors"))
+    _, m = _unet()
+    fe = lambda images, **k: SimpleNamespace(pixel_values=images)   # noqa: E731
+    pipe = StableVideoDiffusionPipeline(vae=_StandInVAE(), image_encoder=_StandInCLIP(), unet=m, feature_extractor=fe)
+    image = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(41))
+    seen = {}
+    orig = pipe.denoise
+
+    def spy(lat, image_latents, image_embeddings, added_time_ids, *a, **k):
+        seen.update(image_latents=image_latents.clone(), image_embeddings=image_embeddings.clone(), ids=added_time_ids.clone())
+        return orig(lat, image_latents, image_embeddings, added_time_ids, *a, **k)
+    pipe.denoise = spy
+    out = pipe(image, height=64, width=64, num_frames=4, num_inference_steps=3, latents=g["latents0"],
+               output_type="latent", generator=torch.Generator().manual_seed(42))
+    assert _rel(seen["image_embeddings"], g["image_embeddings"]) < 2e-3
+    assert _rel(seen["image_latents"], g["image_latents"]) < 2e-3
+    assert torch.equal(seen["ids"].float().cpu(), g["added_time_ids"].float())
+    assert _rel(out.frames, g["final"]) < 2e-2
