@@ -507,3 +507,37 @@ def test_call_from_image_vs_reference_pipeline_golden(golden_dir):
     assert _rel(seen["image_latents"], g["image_latents"]) < 2e-3
     assert torch.equal(seen["ids"].float().cpu(), g["added_time_ids"].float())
     assert _rel(out.frames, g["final"]) < 2e-2
+
+
+def test_call_with_pil_image_and_decoded_outputs():
+    """PIL in, decoded frames out (`output_type` pt / np / pil) with stand-in CLIP / VAE modules: the data-format stages
+    either side of the loop (VaeImageProcessor restatement, anti-aliased CLIP resize on the GPU, chunked decode, tensor2vid)
+    run end to end and agree with each other"""
+    import numpy as np
+    import PIL.Image
+    from types import SimpleNamespace
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+
+    class VAE(_StandInVAE):
+        def decode(self, z, num_frames):
+            x = torch.einsum("oc,bohw->bchw", self.mix.to(z), z)
+            return SimpleNamespace(sample=torch.nn.functional.interpolate(x, scale_factor=8.0, mode="nearest").clamp(-1, 1))
+    _, m = _unet()
+    fe = lambda images, **k: SimpleNamespace(pixel_values=images)   # noqa: E731
+    pipe = StableVideoDiffusionPipeline(vae=VAE(), image_encoder=_StandInCLIP(), unet=m, feature_extractor=fe)
+    rng = np.random.RandomState(3)
+    pil = PIL.Image.fromarray(rng.randint(0, 256, size=(70, 90, 3), dtype=np.uint8))     # resized to 64x64 by preprocess
+    kw = dict(height=64, width=64, num_frames=4, num_inference_steps=2, decode_chunk_size=3)
+    lat = pipe(pil, output_type="latent", generator=torch.Generator().manual_seed(1), **kw).frames
+    assert lat.shape == (1, 4, 4, 8, 8) and torch.isfinite(lat.float()).all()
+    pt = pipe(pil, output_type="pt", generator=torch.Generator().manual_seed(1), **kw).frames
+    assert pt.shape == (1, 4, 3, 64, 64) and 0.0 <= float(pt.min()) and float(pt.max()) <= 1.0
+    npy = pipe(pil, output_type="np", generator=torch.Generator().manual_seed(1), **kw).frames
+    assert npy.shape == (1, 4, 64, 64, 3)
+    assert np.allclose(npy, pt.permute(0, 1, 3, 4, 2).cpu().numpy(), atol=1e-6)          # same run, same seed
+    pils = pipe(pil, output_type="pil", generator=torch.Generator().manual_seed(1), **kw).frames
+    assert len(pils) == 1 and len(pils[0]) == 4 and pils[0][0].size == (64, 64)
+    assert np.abs(np.asarray(pils[0][2]).astype(np.float32) / 255.0 - npy[0, 2]).max() <= 0.5 / 255 + 1e-6
+    # a list of PIL images = a batch of clips
+    two = pipe([pil, pil], output_type="latent", generator=torch.Generator().manual_seed(1), **kw).frames
+    assert two.shape == (2, 4, 4, 8, 8)
