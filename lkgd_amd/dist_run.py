@@ -71,6 +71,10 @@ class DistDenoiser:
         #: replay the step's UNet forward from a recorded launch list (lkgd_amd/replay.py); a frame-sharded rank has
         #: only ~1/8 of the device work per forward and would otherwise wait on the Python module walk
         self.use_replay = os.environ.get("LKGD_NO_REPLAY", "0") != "1"
+        #: bench.py's per-launch GEMM events (ops.GEMM_EVENTS) are taken on every `event_stride`-th Euler step only: an
+        #: event pair per launch is ~600 extra queue packets per forward, which a rank with ~24 ms of device work per
+        #: forward would feel (on one GPU every step is sampled)
+        self.event_stride = 5
 
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, image_embeddings: torch.Tensor,
@@ -119,8 +123,10 @@ class DistDenoiser:
             tok_local = torch.empty(cfg * fl * HW, 8, dtype=torch.float16, device=dev)
             pick = (tok_local.reshape(cfg, fl, HW, 8), tok.reshape(cfg, F, HW, 8)[:, f0:f0 + fl])
         recorded = None
+        events_all = ops.GEMM_EVENTS
         for i, t in enumerate(sch.timesteps_host):
             sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
+            ops.GEMM_EVENTS = events_all if (events_all is not None and i % self.event_stride == self.event_stride // 2) else None
             ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=tok)     # [cfg*F*HW, 8], replicated
             if pick is not None:
                 pick[0].copy_(pick[1])
@@ -155,5 +161,6 @@ class DistDenoiser:
                     n, fs = plan.splits[r], sum(plan.splits[:r])
                     nf[:, fs * HW:(fs + n) * HW].copy_(bv[r, :, :n * HW])
             ops.cfg_euler_step(noise_full, latents, guidance, cfg, sigma, sigma_next, v_prediction=vpred)
+        ops.GEMM_EVENTS = events_all
         sch._step_index = num_inference_steps
         return latents
