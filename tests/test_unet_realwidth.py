@@ -55,24 +55,15 @@ def _rel(a, b):
 
 def test_oracle_real_width_vs_reference_golden(golden, loop_golden, oracle_model):
     """pins the oracle at the real channel widths / head counts (the tiny-config wiring goldens cannot see e.g. a
-    heads-per-level mistake): same weights (checksum), same output to fp32 summation-order noise - one forward, and the
-    2-step loop of the reference's own pipeline `__call__` (BASELINE.json configs[0])"""
-    from oracle.loop import denoise
-    from oracle.scheduler import EulerDiscreteOracle
+    heads-per-level mistake): same weights (checksum), same output to fp32 summation-order noise.  (One forward, ~1 min of
+    CPU; the real-width LOOP golden is checked by the HIP test below - the oracle's loop is pinned at the tiny width.)"""
     o = oracle_model
     ck = float(sum(p.detach().double().abs().sum() for p in o.parameters()))
     assert abs(ck - golden["checksum"].item()) <= 1e-9 * golden["checksum"].item()
     assert abs(ck - loop_golden["checksum"].item()) <= 1e-9 * ck
     with torch.no_grad():
         out = o(golden["in_sample"], golden["in_t"], golden["in_enc"], added_time_ids=golden["in_ids"], return_dict=False)[0]
-        assert _rel(out, golden["out"]) < 1e-4
-        g = loop_golden
-        steps = []
-        fin = denoise(o, EulerDiscreteOracle(), g["latents0"], g["image_latents"], g["image_embeddings"],
-                      g["added_time_ids"], 2, callback=lambda i, t, lat: steps.append(lat.clone()))
-    assert _rel(fin, g["final"]) < 1e-4
-    if steps:
-        assert _rel(steps[0], g["step_latents"][0]) < 1e-4
+    assert _rel(out, golden["out"]) < 1e-4
 
 
 @pytest.mark.gpu
