@@ -129,15 +129,16 @@ class ControlNetSDVModel(_UNetBase):
         self._cond_cache = None
 
     def _cond_tokens(self, cond: torch.Tensor, B: int, F: int, H: int, W: int):
-        """step-invariant part of the conditioning embedding (everything before conv_out), cached per tensor"""
-        key = (cond.data_ptr(), tuple(cond.shape), cond.dtype, cond._version)
-        if self._cond_cache is not None and self._cond_cache[0] == key:
-            return self._cond_cache[1]
+        """step-invariant part of the conditioning embedding (everything before conv_out).  One-entry cache that OWNS its
+        key tensor (identity + in-place version): a new control video at a recycled address is never a hit."""
+        c = self._cond_cache
+        if c is not None and c[0] is cond and c[1] == cond._version:
+            return c[2]
         t, h, w = self.controlnet_cond_embedding.run_until_out(cond.to(self.device))
         if (h, w) != (H, W) or t.shape[0] != B * F * H * W:
             raise ValueError(f"controlnet_cond of shape {tuple(cond.shape)} embeds to a {h}x{w} grid for "
                              f"{t.shape[0] // max(h * w, 1)} frames; the latents are {B * F} frames of {H}x{W}")
-        self._cond_cache = (key, t)
+        self._cond_cache = (cond, cond._version, t)
         return t
 
     @torch.no_grad()

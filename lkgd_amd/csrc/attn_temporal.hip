@@ -154,13 +154,11 @@ extern "C" int lkgd_attn_temporal(const void* q, int32_t ldq, const void* k, int
   long long nblk = (npairs + TP - 1) / TP;
   if (nblk > 0x7fffffffLL) return LKGD_E_SHAPE;
   const float c = scale * 1.4426950408889634f;
-  static bool attr_set = false;
-  if (!attr_set) {
+  LKGD_DEVICE_ONCE_BEGIN
     if (hipFuncSetAttribute((const void*)attn_temporal_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * 32 * TP * TROW) != hipSuccess)
       return LKGD_E_LAUNCH;
-    attr_set = true;
-  }
+  LKGD_DEVICE_ONCE_END
   if (F <= 16)
     hipLaunchKernelGGL(attn_temporal_kernel<16>, dim3((unsigned)nblk, B), dim3(16 * TP), 2 * F * TP * TROW,
                        (hipStream_t)stream, (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv,

@@ -53,3 +53,29 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// hipFuncSetAttribute and the CU count are per DEVICE.  Launchers remember, per device ordinal, that they have set their
+// kernels' attributes (setting one twice is harmless, so a relaxed bit mask is all concurrent callers need).
+#include <atomic>
+struct lkgd_device_once {
+  std::atomic<unsigned long long> mask{0};
+  // returns the current device ordinal (0..63) and whether this launcher still has to initialise it; -1 on error
+  int need(bool* todo) const {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return -1;
+    *todo = ((mask.load(std::memory_order_acquire) >> dev) & 1ull) == 0;
+    return dev;
+  }
+  void done(int dev) { mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
+#define LKGD_DEVICE_ONCE_BEGIN                     \
+  {                                                \
+    static lkgd_device_once once_;                 \
+    bool todo_ = false;                            \
+    const int dev_ = once_.need(&todo_);           \
+    if (dev_ < 0) return LKGD_E_LAUNCH;            \
+    if (todo_) {
+#define LKGD_DEVICE_ONCE_END \
+      once_.done(dev_);      \
+    }                        \
+  }

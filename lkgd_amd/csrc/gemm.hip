@@ -318,16 +318,13 @@ static int check_desc(const lkgd_gemm_desc* d) {
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit);   // gemm_wide.hip
-extern "C" int lkgd_gemm_wide4_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);    // gemm_wide4.hip
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
-extern "C" int lkgd_gemm_pp_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);       // gemm_pp.hip
 
 // tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128 ring,
 // 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320),
 // 5 = force the register-resident row-panel kernel where it applies (plain A, K <= 320),
-// 6 = force the 256x256 ping-pong kernel where it applies
 static int gemm_variant_override = 0;
-extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = v; }
+extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 5) ? v : 0; }
 extern "C" void lkgd_debug_set_gemm_splitk(int on);
 
 // Split-K for the 256x320 kernel on few-row problems (< half the CUs get a tile): the smallest number of EQUAL K slices
@@ -352,21 +349,25 @@ extern "C" void lkgd_debug_set_gemm_splitk(int on) { gemm_splitk_enabled = on !=
 extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   int rc = check_desc(d);
   if (rc != LKGD_OK) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
+  LKGD_DEVICE_ONCE_BEGIN
     if (hipFuncSetAttribute((const void*)lkgd_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) !=
             hipSuccess ||
         hipFuncSetAttribute((const void*)lkgd_gemm_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
                             GEMM2_LDS) != hipSuccess)
       return LKGD_E_LAUNCH;
-    attr_set = true;
-  }
-  static int cus = 0;
-  if (!cus) {
+  LKGD_DEVICE_ONCE_END
+  static std::atomic<int> cus_of[64];
+  int cus = 0;
+  {
     int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LKGD_E_LAUNCH;
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return LKGD_E_LAUNCH;
+    cus = cus_of[dev].load(std::memory_order_relaxed);
+    if (!cus) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LKGD_E_LAUNCH;
+      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      cus_of[dev].store(cus, std::memory_order_relaxed);
+    }
   }
   // GEGLU weights are packed for one tile family (interleave width 80 -> 256x320 tiles, 32 -> 128-wide tiles)
   // the persistent kernels move epilogue rows as 16-byte chunks: 8-channel granularity and 16-byte aligned rows
@@ -380,17 +381,16 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   const int v = gemm_variant_override;
   const bool plain = d->mode == LKGD_A_PLAIN;
   const bool rp_ok = rows16 && plain && d->K <= 320 && d->csplit >= d->K && d->geglu != 80;
-  const bool pp_ok = rows16 && d->geglu != 80 && d->mode != LKGD_A_CONV3X3_C8 && d->M < (1 << 24);
   // (the GEGLU epilogue of the 256x320 kernel is compiled into its plain-linear instantiation only)
   const bool wide_ok = (d->geglu == 0 || (d->geglu == 80 && plain)) && d->mode != LKGD_A_CONV3X3_C8 &&
                        d->M < (1 << 24);
   const bool stream_ok = rows16 && d->geglu != 80;
   const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
-  int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide, 5 = rowpanel, 6 = ping-pong
+  int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide (256x320), 5 = rowpanel
   int wide_ks = 1;
   if (d->geglu == 80) {
     if (!wide_ok) return LKGD_E_SHAPE;
-    pick = v == 7 ? 7 : 4;                                            // 80-wide GEGLU interleave exists only in the 256x320 kernel
+    pick = 4;                                                         // 80-wide GEGLU interleave exists only in the 256x320 kernel
   } else if (v != 0) {
     pick = v;
   } else if (rp_ok && d->M >= 4096 && d->K >= 192 && (d->N != 320 || d->res1)) {
@@ -413,12 +413,10 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   }
   // applicability (forced variants fall back the same way)
   if (pick == 5 && !rp_ok) pick = 1;
-  if (pick == 6 && !pp_ok) pick = 3;
-  if ((pick == 4 || pick == 7) && !wide_ok) pick = 3;
+  if (pick == 4 && !wide_ok) pick = 3;
   if (pick == 3 && (!stream_ok || d->M <= 256)) pick = (d->K >= 960 && d->M > 256) ? 2 : 1;
-  if (d->geglu == 80 && pick != 4 && pick != 7) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the 256x320 kernels
+  if (d->geglu == 80 && pick != 4) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the 256x320 kernels
   if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
-  if (pick == 6) return lkgd_gemm_pp_launch(d, (hipStream_t)stream, cus);
   if (pick == 4) {
     if (v == 4) wide_ks = wide_split(d, tiles_wide, cus);      // forced variant: same slicing rule
     const int ks = wide_ks >= 2 ? wide_ks : 1;
@@ -430,7 +428,6 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
                        (const float*)d->workspace);
     return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
   }
-  if (pick == 7) return lkgd_gemm_wide4_launch(d, (hipStream_t)stream, cus);
   if (pick == 3) return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
   int tiles_n = (d->N + BN - 1) / BN;
   // deep-K problems (3x3 / temporal convs, K >= 960) take the 256x128 three-stage ring: its two K-tiles in flight hide

@@ -154,7 +154,7 @@ __device__ __forceinline__ const half_t* a_chunk(const AGather<NR>& g, int i, in
 }
 
 // ---- lean gather -----------------------------------------------------------------------------------------------
-// For kernels whose accumulators leave few registers (gemm_pp.hip, gemm_wide.hip): per A row a compact descriptor
+// For kernels whose accumulators leave few registers (gemm_wide.hip): per A row a compact descriptor
 // (2 registers) and the current segment's source pointer (2 registers).  The per-segment update has no divisions; the
 // per-tile decomposition of the row index uses a float-reciprocal division (exact for M < 2^24), so deriving a tile's
 // rows does not spike the register pressure inside a K-loop the way a_row()'s integer divisions do.

@@ -321,8 +321,7 @@ extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t st
   const int nk = d->K / 64;
   if (nk < 1 || nk > 5 || d->mode != LKGD_A_PLAIN || d->csplit < d->K) return LKGD_E_SHAPE;
   const int lds = RP_NBUF * RP_BN * d->K * 2 + 8 * 4608;
-  static bool attr_set = false;
-  if (!attr_set) {
+  LKGD_DEVICE_ONCE_BEGIN
     const int mx = RP_NBUF * RP_BN * 320 * 2 + 8 * 4608;
     if (hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
         hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
@@ -330,8 +329,7 @@ extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t st
         hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
         hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
       return LKGD_E_LAUNCH;
-    attr_set = true;
-  }
+  LKGD_DEVICE_ONCE_END
   const int panels = (d->M + RP_ROWS - 1) / RP_ROWS;
   const int tiles_n = (d->N + RP_BN - 1) / RP_BN;
   const int grid = panels < cus ? panels : cus;

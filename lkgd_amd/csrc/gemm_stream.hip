@@ -346,13 +346,11 @@ extern "C" int lkgd_debug_read_stamps(unsigned long long* host_out) {
 #endif
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  LKGD_DEVICE_ONCE_BEGIN
     if (hipFuncSetAttribute((const void*)lkgd_gemm_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SLDS) !=
         hipSuccess)
       return LKGD_E_LAUNCH;
-    attr_set = true;
-  }
+  LKGD_DEVICE_ONCE_END
   int tiles_m = (d->M + SBM - 1) / SBM, tiles_n = (d->N + SBN - 1) / SBN;
   long long ntiles = (long long)tiles_m * tiles_n;
   if (ntiles > 0x7fffffffLL) return LKGD_E_SHAPE;

@@ -380,15 +380,13 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
 
 // ksplit > 1: K is cut into ksplit equal slices (ksplit divides K / 64); the caller runs lkgd_gemm_splitk_reduce afterwards
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  LKGD_DEVICE_ONCE_BEGIN
     const void* fns[6] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>,
                           (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>,
                           (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) != hipSuccess) return LKGD_E_LAUNCH;
-    attr_set = true;
-  }
+  LKGD_DEVICE_ONCE_END
   int tiles_m = (d->M + WBM - 1) / WBM, tiles_n = (d->N + WBN - 1) / WBN;
   if (ksplit < 1 || (d->K / BK) % ksplit || (ksplit > 1 && (!d->workspace || d->geglu))) return LKGD_E_SHAPE;
   long long ntiles = (long long)tiles_m * tiles_n * ksplit;

@@ -305,10 +305,21 @@ class StableVideoDiffusionPipeline:
             image_embeddings = self._encode_image(image, device, num_videos_per_prompt, cfg)
         fps = fps - 1
         if image_latents is None:
-            img = self.image_processor.preprocess(image, height=height, width=width)                 # reference :435
-            noise = _randn_tensor(img.shape, generator, img.device, img.dtype)      # on the image's device, as :449 does
+            img = self.image_processor.preprocess(image, height=height, width=width).to(device)      # reference :466
+            noise = _randn_tensor(img.shape, generator, device, img.dtype)      # drawn for the execution device (:467)
             img = img + noise_aug_strength * noise
+            # reference :470-484: an fp16 VAE with `force_upcast` encodes in fp32 and is cast back right after (so the
+            # decode at the end runs in fp16 again, :643-645)
+            vae_dtype = getattr(self.vae, "dtype", None)
+            needs_upcasting = vae_dtype == torch.float16 and bool(getattr(self.vae.config, "force_upcast", False))
+            if needs_upcasting:
+                self.vae.to(dtype=torch.float32)
+            elif vae_dtype is not None and vae_dtype != img.dtype:
+                img = img.to(vae_dtype)
             image_latents = self._encode_vae_image(img, device, num_videos_per_prompt, cfg)
+            image_latents = image_latents.to(image_embeddings.dtype)                                  # reference :480
+            if needs_upcasting:
+                self.vae.to(dtype=torch.float16)
         image_latents = image_latents.to(device=device, dtype=torch.float16)
         if image_latents.dim() == 4:      # [cfg*B,4,h,w] -> repeat over frames (:488)
             image_latents = image_latents.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)

@@ -17,3 +17,42 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_modifyitems(config, items):
+    """a bare `pytest` on a box without a GPU skips the `gpu` tests instead of failing them (the driver selects with -m)"""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (torch.cuda.is_available() is False)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+C1_SEED = 31   # tests/golden/make_goldens.py: weights of the real-width configs[0] fixtures
+
+
+@pytest.fixture(scope="session")
+def c1_oracle_model():
+    """the fp32 oracle UNet at the REAL width with the weights the reference ran with for the c1 fixtures (regenerated from
+    the seed, rounded to fp16); 6 GB of host memory, shared by every test that needs it"""
+    import torch
+    from oracle import unet as ou
+    o = ou.UNetSpatioTemporalConditionControlNetModel(ou.SVD_CONFIG)
+    ou.init_weights_(o, C1_SEED)
+    with torch.no_grad():
+        for p in o.parameters():
+            p.copy_(p.half().float())
+    return o
+
+
+@pytest.fixture(scope="session")
+def c1_hip_model(c1_oracle_model):
+    import torch
+    from lkgd_amd import unet as pu
+    with torch.device("meta"):
+        m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig())
+    m = m.to_empty(device="cpu")
+    m.load_state_dict(c1_oracle_model.state_dict(), strict=True)
+    return m.half().to("cuda:0")

@@ -615,10 +615,140 @@ def gen_loop_c1(pipe_mod, ref_stock, sched_mod):
     print("loop c1 real width: final std %.4f (2 steps)" % out["final"].std())
 
 
+from fullres_cases import (FULLRES_LK_SEED, FULLRES_SEED, LOOP25_SEED, fullres_inputs, fullres_tracks,   # noqa: E402
+                           seed_conv_fuse_)
+
+
+def _run_pipeline_loop(pipe_mod, unet, sched_mod, image, lat0, px, frames, steps_n, gen_seed):
+    """the reference `__call__` (output_type="latent") with stand-in CLIP / VAE; returns what the loop tests need"""
+    from oracle.scheduler import SchedulerConfig
+    sched = sched_mod.EulerDiscreteScheduler(**SchedulerConfig().__dict__)
+    fe = lambda images, **k: SimpleNamespace(pixel_values=images)   # noqa: E731
+    pipe = pipe_mod.StableVideoDiffusionPipeline(vae=_FakeVAE(), image_encoder=_FakeCLIP(), unet=unet,
+                                                 scheduler=sched, feature_extractor=fe)
+    rec, steps = {}, []
+    orig_forward = unet.forward
+    lc = lat0.shape[2]
+
+    def spy(sample, t, **k):
+        if "enc" not in rec:
+            rec["enc"], rec["ids"] = k["encoder_hidden_states"].clone(), k["added_time_ids"].clone()
+            rec["image_latents"] = sample[:, :, lc:].clone()
+        y = orig_forward(sample, t, **k)
+        print("  step", len(steps), flush=True)
+        return y
+    unet.forward = spy
+    res = pipe(image, height=px, width=px, num_frames=frames, num_inference_steps=steps_n, latents=lat0.clone(),
+               output_type="latent", generator=torch.Generator().manual_seed(gen_seed),
+               callback_on_step_end=lambda p, i, t, kw_: (steps.append(kw_["latents"].clone()), {})[1])
+    unet.forward = orig_forward
+    return {"latents0": lat0, "final": res.frames, "image_embeddings": rec["enc"], "added_time_ids": rec["ids"],
+            "image_latents": rec["image_latents"].contiguous(), "step_latents": torch.stack(steps)}
+
+
+def gen_loop25(pipe_mod, ref_stock, sched_mod):
+    """the 25-step Euler loop of the headline metric at the tiny width: reference `__call__`
+    (pipeline_stable_video_diffusion_trans.py:544-640, scheduler :418-528), every step's latents stored"""
+    kw = {k: v for k, v in TINY.__dict__.items()}
+    with torch.no_grad():
+        unet = ref_stock.UNetSpatioTemporalConditionControlNetModel(**kw)
+        ou.init_weights_(unet, LOOP25_SEED)
+        for p in unet.parameters():
+            p.copy_(p.half().float())
+    g = torch.Generator().manual_seed(LOOP25_SEED + 1)
+    image = torch.rand(1, 3, 64, 64, generator=g)
+    lat0 = torch.randn(1, 4, 4, 8, 8, generator=g)
+    out = _run_pipeline_loop(pipe_mod, unet, sched_mod, image, lat0, 64, 4, 25, LOOP25_SEED + 2)
+    out["checksum"] = torch.tensor(checksum(unet), dtype=torch.float64)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "loop25.safetensors"))
+    print("loop25 (tiny): final std %.4f, step stds %s" % (
+        out["final"].std(), [round(float(s.std()), 3) for s in out["step_latents"][::6]]))
+
+
+def gen_loop25_c1(pipe_mod, ref_stock, sched_mod):
+    """the 25-step loop with the REAL-width UNet on the configs[0] geometry (1 clip x 4 frames x 256x256 px): 25 fp32
+    CPU forwards of the reference (weights as gen_unet_c1), every step's latents stored"""
+    from oracle.unet import SVD_CONFIG
+    with torch.no_grad():
+        unet = ref_stock.UNetSpatioTemporalConditionControlNetModel(**SVD_CONFIG.__dict__)
+        ou.init_weights_(unet, C1_SEED)
+        for p in unet.parameters():
+            p.copy_(p.half().float())
+    g = torch.Generator().manual_seed(C1_SEED + 2)
+    image = torch.rand(1, 3, 256, 256, generator=g)
+    lat0 = torch.randn(1, 4, 4, 32, 32, generator=g)
+    out = _run_pipeline_loop(pipe_mod, unet, sched_mod, image, lat0, 256, 4, 25, C1_SEED + 3)
+    out["checksum"] = torch.tensor(checksum(unet), dtype=torch.float64)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "loop25_c1_realwidth.safetensors"))
+    print("loop25 c1 real width: final std %.4f" % out["final"].std())
+
+
+def gen_unet_fullres(ref_stock):
+    """ONE forward of the reference's stock UNet (unet_spatio_temporal_condition_controlnet.py:358-508) at the REAL width
+    and the FULL latent resolution of configs[1] (72 x 128, S = 9216) with CFG 2 x 2 frames, fp32 on the CPU"""
+    from oracle.unet import SVD_CONFIG
+    inp = fullres_inputs()
+    with torch.no_grad():
+        m = ref_stock.UNetSpatioTemporalConditionControlNetModel(**SVD_CONFIG.__dict__)
+        ou.init_weights_(m, FULLRES_SEED)
+        for p in m.parameters():
+            p.copy_(p.half().float())
+        y = m(inp["sample"], inp["t"], inp["enc"], added_time_ids=inp["ids"], return_dict=False)[0]
+        out = {"checksum": torch.tensor(checksum(m), dtype=torch.float64), "out": y,
+               "out_sum": y.double().sum().reshape(1), "out_abs_sum": y.double().abs().sum().reshape(1)}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_fullres.safetensors"))
+    print("unet fullres: out std %.4f, checksum %.6e" % (out["out"].std(), out["checksum"]))
+
+
+def gen_unet_fullres_lk(ref_lk, fsm_mod):
+    """configs[2] at full resolution: ONE forward of the reference's LKGD UNet (unet_spatio_temporal_condition.py:448-693,
+    domain / flow features) with the patch_FSM hook active in every spatial transformer block (patch_FSM.py:380-441),
+    real width, 72 x 128 latent, CFG 2 x 2 frames, fp32 on the CPU"""
+    from oracle.unet import SVD_CONFIG
+    inp = fullres_inputs(lk=True)
+    track, res = fullres_tracks()
+    with torch.no_grad():
+        m = ref_lk.UNetSpatioTemporalConditionModel(**SVD_CONFIG.__dict__)
+        ou.init_weights_(m, FULLRES_LK_SEED)
+        for p in m.parameters():
+            p.copy_(p.half().float())
+        out = {"checksum": torch.tensor(checksum(m), dtype=torch.float64)}
+        out["lk_nohook"] = m(inp["sample"], inp["t"], inp["enc"], inp["domain"], inp["flow"],
+                             added_time_ids=inp["ids"], return_dict=False)[0]
+        fsm_mod.apply_patch(m, with_spatial_block=True, with_temporal_block=False)
+        fsm_mod.initialize_joint_layers(m)
+        seed_conv_fuse_([b for _, b in m.named_modules() if hasattr(b, "conv_fuse")])
+        fsm_mod.update_patch(m, track=tuple(t.clone() for t in track), track_res=res)
+        fsm_mod.set_joint_attention(m, True)
+        out["lk_fsm"] = m(inp["sample"], inp["t"], inp["enc"], inp["domain"], inp["flow"],
+                          added_time_ids=inp["ids"], return_dict=False)[0]
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_fullres_lk.safetensors"))
+    print("unet fullres lk: nohook std %.4f, fsm std %.4f, delta %.4f" % (
+        out["lk_nohook"].std(), out["lk_fsm"].std(), (out["lk_fsm"] - out["lk_nohook"]).abs().max()))
+
+
 def main():
     assert os.path.isdir(REF), "runs only where /root/reference is mounted"
     install_stubs()
     sys.path.insert(0, REF)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in ("loop25", "loop25_c1", "unet_fullres", "unet_fullres_lk"):     # round-2 fixtures, one at a time
+        for m in ("models", "utils"):
+            _mod(m)
+        sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
+        ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
+                             "models.unet_spatio_temporal_condition_controlnet")
+        if only == "unet_fullres":
+            return gen_unet_fullres(ref_stock)
+        if only == "unet_fullres_lk":
+            ref_lk = load_ref("models/unet_spatio_temporal_condition.py", "models.unet_spatio_temporal_condition")
+            _mod("patch")
+            load_ref("patch/utils.py", "patch.utils")
+            uo = _mod("utils.optical_flow")
+            uo.warp_frames = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("name-only stub"))
+            return gen_unet_fullres_lk(ref_lk, load_ref("patch/patch_FSM.py", "patch.patch_FSM"))
+        pipe_mod = load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans")
+        return (gen_loop25 if only == "loop25" else gen_loop25_c1)(pipe_mod, ref_stock, sched_mod)
     if len(sys.argv) > 1 and sys.argv[1] in ("unet_c1", "loop_c1"):   # only these fixtures (6 GB of fp32 weights, ~1 min each)
         for m in ("models", "utils"):
             _mod(m)
@@ -674,6 +804,10 @@ def main():
     gen_loop(pipe_mod, ref_stock, sched_mod)
     gen_loop_c1(pipe_mod, ref_stock, sched_mod)
     gen_image_ops(pipe_mod)
+    gen_loop25(pipe_mod, ref_stock, sched_mod)
+    gen_loop25_c1(pipe_mod, ref_stock, sched_mod)
+    gen_unet_fullres(ref_stock)
+    gen_unet_fullres_lk(ref_lk, fsm_mod)
 
 
 if __name__ == "__main__":

@@ -185,3 +185,50 @@ def test_fsm_track_tables_match_reference_indexing():
         patch_FSM.track_tables(bad, ctx)
     with pytest.raises(LkgdHipError):
         patch_FSM.track_tables(SimpleNamespace(_tome_info={}, track=None, track_res=None), ctx)
+
+
+def test_lk_fuse_cache_never_serves_a_recycled_address():
+    """the one-entry cache of the latent-knowledge fuse owns its key tensors: 20 freshly allocated, same-shape,
+    different-content embeddings (the allocator hands addresses back) all get their own result; the same objects hit"""
+    from lkgd_amd import unet as pu
+    from lkgd_amd.lk_fuse import lk_fuse, lk_fuse_cached
+    from oracle import unet as ou
+    m = pu.UNetSpatioTemporalConditionModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "quaternion_lora" in n:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    d, f = torch.randn(1, 1, 1000, generator=g), torch.randn(1, 1, 1000, generator=g)
+    for i in range(20):
+        e = torch.randn(2, 1, 1024, generator=g)           # fresh tensor, very likely a recycled address
+        got = lk_fuse_cached(m, e, d, f)
+        assert torch.equal(got, lk_fuse(m, e, d, f)), i
+        assert lk_fuse_cached(m, e, d, f) is got            # same objects, unchanged: a hit
+        del e, got
+    e = torch.randn(2, 1, 1024, generator=g)
+    a = lk_fuse_cached(m, e, d, f)
+    e.mul_(2.0)                                             # in-place change bumps the version: recompute
+    assert not torch.equal(lk_fuse_cached(m, e, d, f), a)
+
+
+def test_controlnet_condition_cache_owns_its_key():
+    from lkgd_amd import controlnet as pc
+    from lkgd_amd import unet as pu
+    from oracle import unet as ou
+    c = pc.ControlNetSDVModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    calls = []
+
+    class _Emb:
+        def run_until_out(self, cond):
+            calls.append(float(cond.sum()))
+            return torch.full((2 * 4 * 8 * 8, 4), float(cond.sum())), 8, 8
+    object.__setattr__(c, "controlnet_cond_embedding", _Emb())
+    c.__dict__["_modules"].pop("controlnet_cond_embedding", None)
+    for i in range(6):
+        cond = torch.full((2, 4, 3, 64, 64), float(i))      # fresh same-shape tensor per "call"
+        t = c._cond_tokens(cond, 2, 4, 8, 8)
+        assert float(t[0, 0]) == float(cond.sum())
+        assert c._cond_tokens(cond, 2, 4, 8, 8) is t
+        del cond, t
+    assert len(calls) == 6

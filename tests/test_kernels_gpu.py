@@ -24,12 +24,12 @@ def _close(got, ref, rtol=4e-3, what=""):
     assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
 
 
-@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel", "pingpong", "wide4"])
+@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel"])
 def ops(request):
     """every GEMM/conv test runs against ALL kernel variants (128x128 two-stage, 256x128 three-stage ring, persistent
     streaming kernel with register epilogue)"""
     from lkgd_amd import _lib, ops
-    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5, "pingpong": 6, "wide4": 7}[request.param])
+    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5}[request.param])
     yield ops
     _lib.lib().lkgd_debug_set_gemm_variant(0)
 

@@ -541,3 +541,41 @@ def test_call_with_pil_image_and_decoded_outputs():
     # a list of PIL images = a batch of clips
     two = pipe([pil, pil], output_type="latent", generator=torch.Generator().manual_seed(1), **kw).frames
     assert two.shape == (2, 4, 4, 8, 8)
+
+
+def test_call_with_fp16_force_upcast_vae():
+    """reference :470-484,:643-645: an fp16 VAE with `force_upcast` is cast to fp32 around the encode, back to fp16 right
+    after, and decodes in fp16; the noise augmentation is drawn for the execution device"""
+    from types import SimpleNamespace
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+    seen = {}
+
+    class VAE(_StandInVAE):
+        def encode(self, image):
+            assert image.dtype == self.mix.dtype, "image / VAE dtype mismatch (the reference would raise here)"
+            seen["encode"] = (image.dtype, image.device.type)
+            return super().encode(image)
+
+        def decode(self, z, num_frames):
+            seen["decode"] = (z.dtype, self.mix.dtype)
+            x = torch.einsum("oc,bohw->bchw", self.mix.to(z), z)
+            return SimpleNamespace(sample=torch.nn.functional.interpolate(x, scale_factor=8.0, mode="nearest").clamp(-1, 1))
+    vae = VAE().half()
+    vae.config.force_upcast = True
+    _, m = _unet()
+    fe = lambda images, **k: SimpleNamespace(pixel_values=images)   # noqa: E731
+    pipe = StableVideoDiffusionPipeline(vae=vae, image_encoder=_StandInCLIP(), unet=m, feature_extractor=fe)
+    image = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(41))
+    kw = dict(height=64, width=64, num_frames=4, num_inference_steps=2)
+    out = pipe(image, output_type="pt", generator=torch.Generator().manual_seed(42), **kw).frames
+    assert seen["encode"] == (torch.float32, "cuda") and vae.dtype == torch.float16
+    assert seen["decode"][1] == torch.float16 and out.shape == (1, 4, 3, 64, 64)
+    # same seed through an fp32 VAE without the flag: same latents up to the fp16 rounding of the VAE weights
+    vae32 = VAE()
+    pipe32 = StableVideoDiffusionPipeline(vae=vae32, image_encoder=_StandInCLIP(), unet=m, feature_extractor=fe)
+    a = pipe(image, output_type="latent", generator=torch.Generator().manual_seed(42), **kw).frames
+    b = pipe32(image, output_type="latent", generator=torch.Generator().manual_seed(42), **kw).frames
+    assert _rel(a, b) < 1e-2
+    # a device generator is accepted (the reference draws the augmentation noise on the execution device)
+    c = pipe32(image, output_type="latent", generator=torch.Generator(device=DEV).manual_seed(5), **kw).frames
+    assert torch.isfinite(c.float()).all()

@@ -13,16 +13,6 @@ from safetensors.torch import load_file
 C1_SEED = 31
 
 
-def _oracle_model():
-    from oracle import unet as ou
-    o = ou.UNetSpatioTemporalConditionControlNetModel(ou.SVD_CONFIG)
-    ou.init_weights_(o, C1_SEED)
-    with torch.no_grad():
-        for p in o.parameters():
-            p.copy_(p.half().float())
-    return o
-
-
 @pytest.fixture(scope="module")
 def golden(golden_dir):
     return load_file(os.path.join(golden_dir, "unet_c1_realwidth.safetensors"))
@@ -34,18 +24,13 @@ def loop_golden(golden_dir):
 
 
 @pytest.fixture(scope="module")
-def oracle_model():
-    return _oracle_model()
+def oracle_model(c1_oracle_model):
+    return c1_oracle_model
 
 
 @pytest.fixture(scope="module")
-def hip_model(oracle_model):
-    from lkgd_amd import unet as pu
-    with torch.device("meta"):
-        m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig())
-    m = m.to_empty(device="cpu")
-    m.load_state_dict(oracle_model.state_dict(), strict=True)
-    return m.half().to("cuda:0")
+def hip_model(c1_hip_model):
+    return c1_hip_model
 
 
 def _rel(a, b):

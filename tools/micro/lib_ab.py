@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time a few GEMM shapes with several builds of the library (tools/micro/lib*.so given on the command line), one child
-process per build, forced variant from VARIANT (default 7)."""
+process per build, forced variant from VARIANT (default 4)."""
 import os
 import subprocess
 import sys

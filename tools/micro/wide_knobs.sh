@@ -6,10 +6,8 @@ set -e
 cd "$(dirname "$0")/../../lkgd_amd/csrc"
 make -s
 OBJS=""
-for s in gemm gemm_stream gemm_rowpanel gemm_pp norm attn_spatial attn_temporal elementwise fsm conv_small image_ops; do OBJS="$OBJS $s.o"; done
-KERNEL=${KERNEL:-gemm_wide}      # KERNEL=gemm_wide4 builds the knob variants of the four-wave kernel instead
-OTHER=$([ "$KERNEL" = gemm_wide ] && echo gemm_wide4 || echo gemm_wide)
-OBJS="$OBJS $OTHER.o"
+for s in gemm gemm_stream gemm_rowpanel norm attn_spatial attn_temporal elementwise fsm conv_small image_ops; do OBJS="$OBJS $s.o"; done
+KERNEL=gemm_wide
 for knob in BASE NONEXT NOBAR "$@"; do
   tag=${knob/=/}
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm -DWIDE_X_$knob -c $KERNEL.hip -o /tmp/${KERNEL}_$tag.o
