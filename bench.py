@@ -30,6 +30,7 @@ if REPO not in sys.path:
 import torch
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+EVENT_CLIP_STRIDE = 4         # GEMM launches are timed with HIP events on clips 0, 4, 8, ... of the timed region
 UNET_TFLOP_C2 = 89.69         # algorithmic TFLOP of one UNet forward at C2
 
 
@@ -123,19 +124,55 @@ def cpu_baseline(args):
                       f"threads (os.cpu_count={os.cpu_count()}); model build {t_build:.0f} s not counted"}
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent never touches
+    the GPU - children are created before any HIP call), rank 0's JSON line goes to the inherited stdout; exit code =
+    the worst child's"""
+    import socket
+    import subprocess
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:          # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
     # LKGD_FORCE_DIST=1: take the sharded runner + RCCL path even with one rank (functional check on a 1-GPU box)
     distributed = world > 1 or os.environ.get("LKGD_FORCE_DIST", "0") == "1"
+    comm_ranks = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -148,6 +185,7 @@ def main():
             dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
+        comm_ranks = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}   # read back from the communicator
 
     from lkgd_amd import ops
     from lkgd_amd.pipeline import StableVideoDiffusionPipeline
@@ -217,16 +255,20 @@ def main():
 
     for _ in range(args.warmup):
         one_clip()
-    if not args.no_kernel_events:
-        ops.GEMM_EVENTS = []
+    # per-launch HIP events of the GEMM family are recorded on every EVENT_CLIP_STRIDE-th timed clip (the first one
+    # included): an event pair per launch is ~15 000 extra queue packets per clip, which the other clips are spared
+    events = [] if not args.no_kernel_events else None
+    clips_sampled = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for c in range(args.steps):
+        sample = events is not None and c % EVENT_CLIP_STRIDE == 0
+        ops.GEMM_EVENTS = events if sample else None
+        clips_sampled += int(sample)
         out = one_clip()
+    ops.GEMM_EVENTS = None
     barrier()
     dt = time.perf_counter() - t0
-    events = ops.GEMM_EVENTS
-    ops.GEMM_EVENTS = None
     if distributed:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -249,14 +291,14 @@ def main():
         sampled = len([i for i in range(args.inference_steps) if i % runner.event_stride == runner.event_stride // 2]) \
             if distributed else args.inference_steps
         scale = args.inference_steps / max(sampled, 1)
-        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_{stream,wide,pp,rowpanel}_kernel (MFMA GEMM / implicit-conv family)",
+        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_{wide,rowpanel,stream}_kernel + lkgd_gemm_kernel (MFMA GEMM / implicit-conv family)",
                     "achieved": round(achieved, 2),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "launches": len(events),
                     "avg_launch_us": round(tot_ms * 1e3 / len(events), 2),
-                    "gemm_share_of_wall": round(tot_ms * 1e-3 * scale / dt, 3),
-                    "launches_timed": "every launch of the timed region" if not distributed else
-                                      f"the launches of {sampled} of {args.inference_steps} Euler steps per clip"}
+                    "gemm_share_of_wall": round(tot_ms * 1e-3 * scale * args.steps / max(clips_sampled, 1) / dt, 3),
+                    "launches_timed": f"every GEMM launch of {clips_sampled} of the {args.steps} timed clips" + (
+                        "" if not distributed else f", {sampled} of {args.inference_steps} Euler steps each")}
 
     if rank == 0:
         cpu = None
@@ -278,7 +320,7 @@ def main():
                                    + (" [TINY UNET - INVALID]" if args.tiny else ""),
                        "unet": "random-init SVD shapes (320,640,1280,1280), heads (5,10,20,20), 1.52 B params",
                        "parallelism": "single GPU" if world == 1 else f"cfg x frame shards over {world} GPUs"},
-            "finite_output": finite,
+            "finite_output": finite, "rccl_ranks": comm_ranks,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

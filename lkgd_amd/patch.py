@@ -12,9 +12,9 @@ temporal-attention kernels with a K/V batch permutation + the zero-init ``conv1n
 class NAME in the MRO (patch/utils.py:4-16).  The boolean-mask partner selection (:466-468) becomes a static int32
 permutation computed on the host from the 4-entry mask (masks are constants, utils/util.py:600-606).
 
-LoRA-mask plumbing (``set_patch_lora_mask`` / ``hack_lora_forward`` / ``initialize_joint_lora`` :57-92,:872-936) targets
-peft-wrapped Linear layers during training; inference merges LoRA into the base weights, so these
-entry points exist and raise with that explanation rather than silently doing nothing.
+LoRA-mask plumbing (``set_patch_lora_mask`` / ``hack_lora_forward`` / ``initialize_joint_lora`` :57-92,:872-936) works on the
+``lkgd_amd.lora.Linear`` wrappers: the reference's INFERENCE loader calls it (utils/util.py:598-604).  A per-entry masked
+adapter is a per-entry weight here (lkgd_amd/lora.py), not an extra low-rank GEMM.
 """
 from __future__ import annotations
 
@@ -132,15 +132,76 @@ def set_joint_attention_mask(model, joint_attn_mask):
     return model
 
 
-def _training_only(name):
-    def f(*a, **k):
-        raise LkgdHipError(f"patch.{name} manipulates peft LoRA layers at training time; the MI355X inference path "
-                           "expects LoRA merged into the base weights (W += B@A*scale) before load_state_dict")
-    f.__name__ = name
-    return f
+# ---- masked-LoRA plumbing (patch/patch.py:57-92,:872-936); execution: lkgd_amd/lora.py + lkgd_amd/unet.py ----------
+def _models(model):
+    dm = _model(model)
+    return [dm] + ([model.controlnet] if getattr(model, "controlnet", None) is not None else [])
 
 
-set_patch_lora_mask = _training_only("set_patch_lora_mask")
-hack_lora_forward = _training_only("hack_lora_forward")
-initialize_joint_lora = _training_only("initialize_joint_lora")
-set_joint_layer_requires_grad = _training_only("set_joint_layer_requires_grad")
+def set_patch_lora_mask(model, lora_name, lora_mask):
+    """patch/patch.py:872-896: one bool per batch entry; K / V of the joint attention take the inverted mask"""
+    from .lora import Linear
+    mask = torch.tensor(lora_mask, dtype=torch.bool)
+    for dm in _models(model):
+        if not hasattr(dm, "lora_mask"):
+            dm.lora_mask = dict()
+        dm.lora_mask[lora_name] = mask
+        for name, m in dm.named_modules():
+            if isinstance(m, Linear):
+                if not hasattr(m, "lora_mask"):
+                    m.lora_mask = dict()
+                m.lora_mask[lora_name] = ~mask if ("attn1n.to_k" in name or "attn1n.to_v" in name) else mask
+        if hasattr(dm, "invalidate"):
+            dm.invalidate()
+    return model
+
+
+def hack_lora_forward(model):
+    """patch/patch.py:912-922: every LoRA-wrapped projection switches to the masked forward (:57-92)"""
+    from .lora import Linear
+    for dm in _models(model):
+        for _, m in dm.named_modules():
+            if isinstance(m, Linear):
+                m._lkgd_masked = True
+        if hasattr(dm, "invalidate"):
+            dm.invalidate()
+    return model
+
+
+def initialize_joint_lora(model, adapter_name, joint_adapter_name):
+    """patch/patch.py:185-197,:925-936: attn1n's adapter `joint_adapter_name` := attn1's adapter `adapter_name`"""
+    from .lora import Linear
+    for dm in _models(model):
+        for _, blk in dm.named_modules():
+            if not getattr(blk, "_lkgd_patched", False) or not hasattr(blk, "attn1n"):
+                continue
+            for name, m in blk.attn1n.named_modules():
+                if not isinstance(m, Linear):
+                    continue
+                src = blk.attn1.get_submodule(name)
+                for layer_name in m.adapter_layer_names:
+                    dst_dict, src_dict = getattr(m, layer_name), getattr(src, layer_name)
+                    if joint_adapter_name in dst_dict:
+                        dst_dict[joint_adapter_name].load_state_dict(src_dict[adapter_name].state_dict())
+        if hasattr(dm, "invalidate"):
+            dm.invalidate()
+    return model
+
+
+def set_joint_layer_requires_grad(model, adapter_names, requires_grad):
+    """patch/patch.py:111-133,:898-910 (a training knob; literal): attn1n's adapter parameters and the post layers"""
+    from .lora import Linear
+    for dm in _models(model):
+        for _, blk in dm.named_modules():
+            if not getattr(blk, "_lkgd_patched", False) or not hasattr(blk, "attn1n"):
+                continue
+            for _, m in blk.attn1n.named_modules():
+                if isinstance(m, Linear):
+                    for layer_name in m.adapter_layer_names:
+                        for key, layer in getattr(m, layer_name).items():
+                            if key in adapter_names:
+                                layer.requires_grad_(requires_grad)
+            for post in ("conv1n", "scale1n"):
+                if hasattr(blk, post):
+                    getattr(blk, post).requires_grad_(requires_grad)
+    return model

@@ -97,6 +97,9 @@ class Ctx:
         self.joint_blocks = None
         self.spatial_partner: Optional[torch.Tensor] = None   # joint attention maps (patch API)
         self.temporal_partner: Optional[torch.Tensor] = None
+        self.entry_partner: Optional[List[int]] = None
+        self.lora = None               # lkgd_amd.lora.EntryPlan when the model carries LoRA wrappers (masked LoRA forward)
+        self.xb_runs: Optional[List[torch.Tensor]] = None     # cross-attention bias tables per entry run (LoRA on attn2)
 
     @property
     def frames_sharded(self) -> bool:
@@ -172,31 +175,80 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(kv, self.inner_dim, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(self.inner_dim, query_dim, bias=True), nn.Dropout(0.0)])
 
-    def pack_self(self, norm: Optional[nn.LayerNorm] = None):
-        """fused QKV weight; with `norm` the preceding LayerNorm's affine is folded in (QKV then carries a bias)"""
-        w = torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach(), self.to_v.weight.detach()], dim=0)
+    def pack_self(self, norm: Optional[nn.LayerNorm] = None, adapters=((), (), (), ())):
+        """fused QKV weight; with `norm` the preceding LayerNorm's affine is folded in (QKV then carries a bias).
+        `adapters` = the LoRA adapter names folded into (to_q, to_k, to_v, to_out.0) for this variant (lkgd_amd/lora.py)"""
+        aq, ak, av, ao = adapters
+        w = torch.cat([_eff_weight(self.to_q, aq), _eff_weight(self.to_k, ak), _eff_weight(self.to_v, av)], dim=0)
         bqkv = None
         if norm is not None:
             w, bqkv = _fold_ln(norm, w, None)
             bqkv = bqkv.contiguous()
         return SimpleNamespace(wqkv=pack_linear(w), bqkv=bqkv,
-                               wo=pack_linear(self.to_out[0].weight), bo=_f32(self.to_out[0].bias))
+                               wo=pack_linear(_eff_weight(self.to_out[0], ao)), bo=_f32(self.to_out[0].bias))
 
-    def fold_cross(self):
-        """single key/value token => attn2(x, e) == to_out(to_v(e)): returns (W_o @ W_v [C,1024] fp32, b_o)"""
-        wo = self.to_out[0].weight.detach().to(torch.float32)
-        wv = self.to_v.weight.detach().to(torch.float32)
+    def fold_cross(self, adapters=((), ())):
+        """single key/value token => attn2(x, e) == to_out(to_v(e)): returns (W_o @ W_v [C,1024] fp32, b_o); LoRA on
+        to_q / to_k of a one-token attention is dead (softmax over one key)"""
+        av, ao = adapters
+        wo = _eff_weight(self.to_out[0], ao).to(torch.float32)
+        wv = _eff_weight(self.to_v, av).to(torch.float32)
         return wo @ wv, _f32(self.to_out[0].bias)
 
 
-def _pack_joint_post(block, pk, spatial: bool):
+def _eff_weight(lin, adapters=()) -> torch.Tensor:
+    """weight of a projection with the named LoRA adapters folded in (fp32 when the layer is wrapped)"""
+    if hasattr(lin, "effective_weight"):
+        return lin.effective_weight(adapters)
+    return lin.weight.detach()
+
+
+def _gemm_runs(ctx: "Ctx", a: torch.Tensor, out: torch.Tensor, pick, *, N: int, K: int, rowmap=None, res1=None,
+               res2=None, **kw) -> None:
+    """masked-LoRA form of a projection over all T rows: one launch per run of consecutive batch entries that share a
+    weight variant (lkgd_amd/lora.py).  pick(i) -> (w, bias, rowbias table or None) of run i; a row map is shifted to the
+    run's first row (idx(m) = ((m / d1) * m1 + m % d2 + c0) % md with the run start a multiple of d1 and d2)"""
+    rows = ctx.F * ctx.HW
+    for i, (b0, b1) in enumerate(ctx.lora.runs):
+        r0, r1 = b0 * rows, b1 * rows
+        w, bias, rb = pick(i)
+        rm = None
+        if rb is not None:
+            if r0 % rowmap[0] or r0 % rowmap[2]:
+                raise LkgdHipError("internal: entry run does not start on a row-map period")
+            rm = (rowmap[0], rowmap[1], rowmap[2], rowmap[3],
+                  (rowmap[4] if len(rowmap) > 4 else 0) + (r0 // rowmap[0]) * rowmap[1])
+        ops.gemm(a[r0:r1], w, out[r0:r1], M=r1 - r0, N=N, K=K, bias=bias, rowbias=rb, rowmap=rm,
+                 res1=res1[r0:r1] if res1 is not None else None, res2=res2[r0:r1] if res2 is not None else None, **kw)
+
+
+def _attn_variant(block, which: str, ctx: "Ctx", run: int, spatial: bool):
+    """packed weights of block.attn1 / block.attn1n for entry run `run` (built on demand per adapter subset, cached on
+    the block's pack).  K / V of the joint attention see the PARTNER entry's adapters: their input rows are consumed by
+    the partner (patch/patch.py:466-468,:889-892)."""
+    pk = block._pk
+    attn = block.attn1 if which == "a1" else block.attn1n
+    P = ctx.lora
+    jn = which == "a1n"
+    key = (which, P.adapters(attn.to_q, run), P.adapters(attn.to_k, run, jn), P.adapters(attn.to_v, run, jn),
+           P.adapters(attn.to_out[0], run))
+    v = pk.var.get(key)
+    if v is None:
+        v = attn.pack_self(block.norm1, key[1:])
+        if jn:
+            _pack_joint_post(block, v, spatial, key[4])
+        pk.var[key] = v
+    return v
+
+
+def _pack_joint_post(block, pk, spatial: bool, out_adapters=()):
     """fold the joint branch's post-processing (patch/patch.py:484-494) into attn1n's out-projection:
     conv:      conv1n(to_out(a))  = a @ (Wc Wo)^T + Wc bo
     scale:     scale1n * to_out(a) = a @ (diag(s) Wo)^T + s * bo
     conv_fuse: cat(o[mask], o[~mask]) @ Wc^T, chunked back = own/partner halves of Wc times Wo (K = 2C, spatial only;
                the temporal branch applies no post for 'conv_fuse', patch.py:647-650)"""
     post = getattr(block, "post", "conv")
-    wo = block.attn1n.to_out[0].weight.detach().to(torch.float32)
+    wo = _eff_weight(block.attn1n.to_out[0], out_adapters).to(torch.float32)
     bo = block.attn1n.to_out[0].bias.detach().to(torch.float32)
     C_ = wo.shape[0]
     if post == "conv":
@@ -290,6 +342,7 @@ class BasicTransformerBlock(nn.Module):
             _pack_joint_post(self, pk, spatial=True)
         if hasattr(self, "conv_fuse"):      # FSM hook (lkgd_amd/patch_FSM.py)
             pk.wfuse, pk.bfuse = pack_conv3x3(self.conv_fuse.weight), _f32(self.conv_fuse.bias)
+        pk.var = {}                         # masked-LoRA weight variants, built on demand (_attn_variant)
         self._pk = pk
 
     def run(self, ctx: Ctx, h: torch.Tensor) -> torch.Tensor:
@@ -297,10 +350,23 @@ class BasicTransformerBlock(nn.Module):
         heads = self.attn1.heads
         ln = ops.layernorm(h, None, None, 1e-5)
         qkv = ctx.new(T, 3 * Cc)
-        ops.gemm(ln, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
+        if ctx.lora is None:
+            ops.gemm(ln, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
+        else:
+            va = [_attn_variant(self, "a1", ctx, i, True) for i in range(len(ctx.lora.runs))]
+            _gemm_runs(ctx, ln, qkv, lambda i: (va[i].wqkv, va[i].bqkv, None), N=3 * Cc, K=Cc)
         att = ctx.new(T, Cc)
         ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, heads)
         h1 = ctx.new(T, Cc)
+        if ctx.lora is not None:
+            if getattr(self, "_lkgd_fsm", False) and self.enable_joint_attention:
+                raise LkgdHipError("masked LoRA together with the FSM hook is not supported")
+            _gemm_runs(ctx, att, h1, lambda i: (va[i].wo, va[i].bo, ctx.xb_runs[i][ctx.b0:, pk.xoff:pk.xoff + Cc]),
+                       N=Cc, K=Cc, rowmap=ops.rowmap_div(ctx.F * ctx.HW), res1=h)
+            if self.enable_joint_attention and hasattr(self, "attn1n"):
+                h1 = self._joint(ctx, ln, h1)
+            ln3 = ops.layernorm(h1, None, None, 1e-5)
+            return _ff(ctx, pk.ff, ln3, res1=h1)
         if getattr(self, "_lkgd_fsm", False) and self.enable_joint_attention:
             # the track fuse reads attn1(x) + x BEFORE cross-attention: the folded attn2 bias is added by its last kernels
             ops.gemm(att, pk.a1.wo, h1, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=h)
@@ -323,15 +389,25 @@ class BasicTransformerBlock(nn.Module):
         if ctx.spatial_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set (patch.set_joint_attention_mask)")
         qkv = ctx.new(T, 3 * Cc)
-        ops.gemm(ln, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
+        vj = None
+        if ctx.lora is None:
+            ops.gemm(ln, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
+        else:
+            vj = [_attn_variant(self, "a1n", ctx, i, True) for i in range(len(ctx.lora.runs))]
+            _gemm_runs(ctx, ln, qkv, lambda i: (vj[i].wqkv, vj[i].bqkv, None), N=3 * Cc, K=Cc)
         att = ctx.new(T, Cc)
         ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, self.attn1n.heads,
                          kv_batch_map=ctx.spatial_partner)
         out = ctx.new(T, Cc)
         js = float(self.joint_scale)
         if pk.post != "conv_fuse":
-            ops.gemm(att, pk.jw, out, M=T, N=Cc, K=Cc, bias=pk.jb, s_acc=js, res1=h1)
+            if vj is None:
+                ops.gemm(att, pk.jw, out, M=T, N=Cc, K=Cc, bias=pk.jb, s_acc=js, res1=h1)
+            else:
+                _gemm_runs(ctx, att, out, lambda i: (vj[i].jw, vj[i].jb, None), N=Cc, K=Cc, s_acc=js, res1=h1)
             return out
+        if vj is not None:
+            raise LkgdHipError("masked LoRA with post='conv_fuse' joint layers is not supported")
         # conv_fuse: the i-th masked and i-th unmasked entry blocks are fused pairwise (:488-493) - one two-source GEMM
         # per entry block, own rows | partner rows along K
         if ctx.joint_blocks is None:
@@ -401,6 +477,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         if hasattr(self, "attn1n"):
             pk.a1n = self.attn1n.pack_self(self.norm1)
             _pack_joint_post(self, pk, spatial=False)
+        pk.var = {}
         self._pk = pk
 
     def run(self, ctx: Ctx, h_s: torch.Tensor, posemb: torch.Tensor, alpha: float, order: str) -> torch.Tensor:
@@ -411,7 +488,16 @@ class TemporalBasicTransformerBlock(nn.Module):
         m1 = _ff(ctx, pk.ffin, lnin, res1=h_s, rowbias=posemb, rowmap=fmap)        # ff_in(norm_in(m0)) + m0
         ln1 = ops.layernorm(m1, None, None, 1e-5)
         att = ctx.new(T, Cc)
-        if not ctx.frames_sharded:
+        va = None
+        if ctx.lora is not None:
+            if ctx.frames_sharded:
+                raise LkgdHipError("masked LoRA is not available under frame sharding")
+            va = [_attn_variant(self, "a1", ctx, i, False) for i in range(len(ctx.lora.runs))]
+            qkv = ctx.new(T, 3 * Cc)
+            _gemm_runs(ctx, ln1, qkv, lambda i: (va[i].wqkv, va[i].bqkv, None), N=3 * Cc, K=Cc)
+            ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
+                              self.attn1.heads)
+        elif not ctx.frames_sharded:
             qkv = ctx.new(T, 3 * Cc)
             ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
             ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
@@ -438,7 +524,12 @@ class TemporalBasicTransformerBlock(nn.Module):
         else:
             raise ValueError(order)
         m2 = ctx.new(T, Cc)
-        ops.gemm(att, pk.a1.wo, m2, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=m1, rowbias=xtab, rowmap=xmap)
+        if va is None:
+            ops.gemm(att, pk.a1.wo, m2, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=m1, rowbias=xtab, rowmap=xmap)
+        else:
+            b_off = ctx.b0 if order == "batch_major" else 0
+            _gemm_runs(ctx, att, m2, lambda i: (va[i].wo, va[i].bo, ctx.xb_runs[i][b_off:, pk.xoff:pk.xoff + Cc]),
+                       N=Cc, K=Cc, rowmap=xmap, res1=m1)
         if self.enable_joint_attention and hasattr(self, "attn1n"):
             m2 = self._joint(ctx, ln1, m2)
         ln3 = ops.layernorm(m2, None, None, 1e-5)
@@ -451,12 +542,20 @@ class TemporalBasicTransformerBlock(nn.Module):
         if ctx.temporal_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
         qkv = ctx.new(T, 3 * Cc)
-        ops.gemm(ln1, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
+        vj = None
+        if ctx.lora is None:
+            ops.gemm(ln1, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
+        else:
+            vj = [_attn_variant(self, "a1n", ctx, i, False) for i in range(len(ctx.lora.runs))]
+            _gemm_runs(ctx, ln1, qkv, lambda i: (vj[i].wqkv, vj[i].bqkv, None), N=3 * Cc, K=Cc)
         att = ctx.new(T, Cc)
         ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
                           self.attn1n.heads, kv_b_map=ctx.temporal_partner)
         out = ctx.new(T, Cc)
-        ops.gemm(att, pk.jw, out, M=T, N=Cc, K=Cc, bias=pk.jb, res1=m2)   # post folded in; joint_scale is not applied here
+        if vj is None:   # post folded in; joint_scale is not applied here
+            ops.gemm(att, pk.jw, out, M=T, N=Cc, K=Cc, bias=pk.jb, res1=m2)
+        else:
+            _gemm_runs(ctx, att, out, lambda i: (vj[i].jw, vj[i].jb, None), N=Cc, K=Cc, res1=m2)
         return out
 
 
@@ -959,6 +1058,9 @@ class _UNetBase(nn.Module):
         folded = [a.fold_cross() for a in self._cross_reg]
         pk.w_x = torch.cat([w for w, _ in folded], dim=0).to(torch.float16).contiguous()
         pk.b_x = torch.cat([b for _, b in folded]).contiguous()
+        pk.x_var = {}                      # masked-LoRA variants of the folded cross-attention matrix (_cross_tables)
+        from . import lora as _lora
+        pk.has_lora = bool(_lora.lora_layers(self))
         self._pk = pk
 
     # ---- forward pieces ---------------------------------------------------------------------------------------
@@ -993,6 +1095,23 @@ class _UNetBase(nn.Module):
         e = encoder_hidden_states.to(device=ctx.device, dtype=torch.float16).reshape(Bt, -1).contiguous()
         ctx.xb_all = torch.empty(Bt, pk.w_x.shape[0], dtype=torch.float16, device=ctx.device)
         ops.gemm(e, pk.w_x, ctx.xb_all, M=Bt, N=pk.w_x.shape[0], K=pk.w_x.shape[1], bias=pk.b_x)
+        if ctx.lora is None:
+            return
+        # LoRA on attn2.to_v / to_out.0: one folded matrix per distinct adapter subset, one table per entry run (a run's
+        # rows look up ANY context row - the temporal interleave of App. C11 - but always with the run's own weights)
+        ctx.xb_runs = []
+        for i in range(len(ctx.lora.runs)):
+            key = tuple((ctx.lora.adapters(a.to_v, i), ctx.lora.adapters(a.to_out[0], i)) for a in self._cross_reg)
+            if not any(k[0] or k[1] for k in key):
+                ctx.xb_runs.append(ctx.xb_all)
+                continue
+            wx = pk.x_var.get(key)
+            if wx is None:
+                wx = torch.cat([a.fold_cross(k)[0] for a, k in zip(self._cross_reg, key)], dim=0)
+                wx = pk.x_var[key] = wx.to(torch.float16).contiguous()
+            tab = torch.empty_like(ctx.xb_all)
+            ops.gemm(e, wx, tab, M=Bt, N=wx.shape[0], K=wx.shape[1], bias=pk.b_x)
+            ctx.xb_runs.append(tab)
 
     def _joint_maps(self, ctx: Ctx):
         """partner permutations of the patch API (patch/patch.py:454-475), computed on the host from the 4-entry mask"""
@@ -1010,11 +1129,13 @@ class _UNetBase(nn.Module):
             p[m] = idx[~m]
             if group is not None:
                 p = p.reshape(-1, group).flip(1).reshape(-1)
-            return p.to(torch.int32).to(ctx.device)
+            return p.to(torch.int32)
         if ctx.N % len(mask) or ctx.B % len(mask):
             raise LkgdHipError("joint_attn_mask length must divide the UNet batch")
-        ctx.spatial_partner = partner(ctx.N, ctx.F if flip else None)
-        ctx.temporal_partner = partner(ctx.B, None)
+        ctx.spatial_partner = partner(ctx.N, ctx.F if flip else None).to(ctx.device)
+        tp = partner(ctx.B, None)
+        ctx.entry_partner = tp.tolist()                       # batch-entry level partner (host copy, for the LoRA plan)
+        ctx.temporal_partner = tp.to(ctx.device)
         # entry blocks for post == "conv_fuse": i-th masked block <-> i-th unmasked block (no flip, patch.py:488-493)
         ml = [bool(v) for v in torch.as_tensor(mask).tolist()]
         per = ctx.N // len(ml)
@@ -1057,10 +1178,15 @@ class _UNetBase(nn.Module):
         ctx = Ctx(B, F, H, W, self.device, shard)
         pk = self._pk
         self._time_embed(ctx, timestep, added_time_ids)
-        self._cross_tables(ctx, encoder_hidden_states)
         if shard is not None and getattr(self, "_joint_attn_mask", None) is not None:
             raise LkgdHipError("joint attention (patch API) pairs batch entries and is not available under sharding")
         self._joint_maps(ctx)
+        if pk.has_lora:
+            if shard is not None:
+                raise LkgdHipError("LoRA wrappers under sharding: merge them first (lkgd_amd.lora.merge_lora)")
+            from . import lora as _lora
+            ctx.lora = _lora.entry_plan(self, ctx.B, ctx.entry_partner)
+        self._cross_tables(ctx, encoder_hidden_states)
         h = ctx.new(ctx.T, pk.w_in.shape[0])
         ops.gemm(tokens, pk.w_in, h, M=ctx.T, N=pk.w_in.shape[0], K=128, bias=pk.b_in, mode=ops.A_CONV3X3_C8, Cin=8,
                  conv=(H, W, H, W, 1, 0))

@@ -102,6 +102,35 @@ def temporal_block_forward(block: TemporalBasicTransformerBlock, hidden_states, 
     return h[None, :].reshape(b, s, num_frames, c).permute(0, 2, 1, 3).reshape(b * num_frames, s, c)
 
 
+def apply_joint(model: nn.Module, joint_mask, post: str = "conv", flip: bool = False, spatial: bool = True,
+                temporal: bool = True) -> None:
+    """patch.apply_patch + initialize_joint_layers + set_joint_attention_mask on an oracle UNet (patch.py:719-817,:966-996):
+    the spatial / temporal transformer blocks get ``attn1n`` + post layer and the joint forwards above.  The frame count
+    for ``flip`` comes from the sample shape the reference records in a forward pre-hook (:691-697)."""
+    mask = torch.as_tensor(joint_mask, dtype=torch.bool)
+    info = {"size": None}
+    model.register_forward_pre_hook(lambda mod, args: info.__setitem__("size", args[0].shape))
+    for m in model.modules():
+        if spatial and type(m) is BasicTransformerBlock:
+            initialize_joint_layers(m, post)
+            m.enable_joint_attention = True
+            m.forward = functools.partial(_joint_spatial_forward, m, mask, flip, info)
+        elif temporal and type(m) is TemporalBasicTransformerBlock:
+            initialize_joint_layers(m, post)
+            m.enable_joint_attention = True
+            m.forward = functools.partial(_joint_temporal_forward, m, mask)
+
+
+def _joint_spatial_forward(block, mask, flip, info, hidden_states, encoder_hidden_states=None, **_):
+    return basic_block_forward(block, hidden_states, encoder_hidden_states, mask, block.enable_joint_attention, flip,
+                               info["size"][1] if info["size"] is not None else None)
+
+
+def _joint_temporal_forward(block, mask, hidden_states, num_frames=None, encoder_hidden_states=None, **_):
+    return temporal_block_forward(block, hidden_states, num_frames, encoder_hidden_states, mask,
+                                  block.enable_joint_attention)
+
+
 # ------------------------------------------------------------------------------------------------ FSM hook (a15)
 def initialize_fsm_layers(block: nn.Module) -> None:
     """patch_FSM.py:92-97: zero-initialised 3x3 ``conv_fuse`` on 2C channels"""

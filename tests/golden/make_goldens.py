@@ -192,9 +192,62 @@ def install_stubs():
     pu.DiffusionPipeline = DiffusionPipeline
 
     _mod("peft"); _mod("peft.tuners"); _mod("peft.tuners.lora")
+    # peft is not installed: bookkeeping-only stand-in for its BaseTunerLayer [EXT peft tuners_utils.py] (which adapters
+    # are active / merged, the base-layer accessor) so that the reference's VENDORED peft layer
+    # (/root/reference/models/lora_layer.py - the arithmetic: update_layer, get_delta_weight, merge, forward) can be
+    # executed and patch.py's `Linear` / `lora_forward_hack` (:57-92) run over it
+    tu_ = _mod("peft.tuners.tuners_utils")
+
+    class BaseTunerLayer:
+        adapter_layer_names = ()
+        other_param_names = ()
+        _disable_adapters = False
+        _active_adapter = "default"
+        merged_adapters = []
+
+        def get_base_layer(self):
+            base = self
+            while hasattr(base, "base_layer"):
+                base = base.base_layer
+            return base
+
+        @property
+        def weight(self):
+            return self.get_base_layer().weight
+
+        @property
+        def bias(self):
+            return self.get_base_layer().bias
+
+        @property
+        def merged(self):
+            return bool(self.merged_adapters)
+
+        @property
+        def disable_adapters(self):
+            return self._disable_adapters
+
+        @property
+        def active_adapter(self):
+            return self._active_adapter
+
+        @property
+        def active_adapters(self):
+            return [self._active_adapter] if isinstance(self._active_adapter, str) else self._active_adapter
+
+        def set_adapter(self, adapter_names):
+            self._active_adapter = [adapter_names] if isinstance(adapter_names, str) else list(adapter_names)
+    tu_.BaseTunerLayer = BaseTunerLayer
+    tu_.check_adapters_to_merge = lambda module, adapter_names=None: list(adapter_names or module.active_adapters)
+    _mod("peft.utils")
+    import contextlib
+    _mod("peft.utils.integrations").gather_params_ctx = lambda *a, **k: contextlib.nullcontext()
+    _mod("peft.utils.other").transpose = lambda w, fan_in_fan_out: w.T if fan_in_fan_out else w
+    _mod("peft.tuners.lora.config").LoraConfig = type("LoraConfig", (), {})
     pl = _mod("peft.tuners.lora.layer")
-    pl.Linear = type("Linear", (nn.Module,), {})
-    pl.BaseTunerLayer = type("BaseTunerLayer", (), {})
+    vendored = load_ref("models/lora_layer.py", "ref_lora_layer")
+    pl.Linear = vendored.Linear
+    pl.BaseTunerLayer = BaseTunerLayer
     _mod("core_qnn")
     q = _mod("core_qnn.quaternion_layers")
     q.QuaternionLinearAutograd = ob.QuaternionLinearAutograd
@@ -619,6 +672,65 @@ from fullres_cases import (FULLRES_LK_SEED, FULLRES_SEED, LOOP25_SEED, fullres_i
                            seed_conv_fuse_)
 
 
+def gen_patch_lora(patch_mod, ref_stock):
+    """the inference loader's LoRA sequence (utils/util.py:560-606) on the reference's own classes: `patch.apply_patch` +
+    `initialize_joint_layers` on the stock UNet, adapters xy_lora / yx_lora as vendored `models/lora_layer.py::Linear`
+    wrappers on every attention projection, `set_adapter`, `patch.hack_lora_forward` (patch.py:57-92),
+    `set_patch_lora_mask` ([0,1,0,1] / [1,0,1,0], inverted on attn1n.to_k / to_v :889-892), `set_joint_attention_mask`;
+    one forward of the batch [u_x, u_y, c_x, c_y] per variant"""
+    from lora_cases import ADAPTERS, ALPHA, JOINT_MASK, MASKS, RANK, lora_inputs, seed_joint_and_lora_
+    LoraLinear = sys.modules["peft.tuners.lora.layer"].Linear
+    kw = {k: v for k, v in TINY.__dict__.items()}
+    inp = lora_inputs()
+    out = {}
+    with torch.no_grad():
+        m = ref_stock.UNetSpatioTemporalConditionControlNetModel(**kw)
+        ou.init_weights_(m, WSEED + 9)
+        for p in m.parameters():
+            p.copy_(p.half().float())
+        out["checksum_base"] = torch.tensor(checksum(m), dtype=torch.float64)
+        patch_mod.apply_patch(m, flip=False, with_temporal_block=True, with_spatial_block=True)
+        patch_mod.initialize_joint_layers(m)
+        for name, mod in list(m.named_modules()):          # peft inject_adapter: suffix match on the target names
+            if isinstance(mod, nn.Linear) and any(name.endswith("." + t) for t in ("to_q", "to_k", "to_v", "to_out.0")) \
+                    and ".lora_" not in name and not name.endswith("base_layer"):
+                parent = m.get_submodule(name.rpartition(".")[0])
+                child = name.rpartition(".")[2]
+                w = LoraLinear(mod, ADAPTERS[0], r=RANK, lora_alpha=ALPHA)
+                for a in ADAPTERS[1:]:
+                    w.update_layer(a, RANK, lora_alpha=ALPHA, lora_dropout=0.0, init_lora_weights=True, use_rslora=False)
+                if isinstance(parent, nn.ModuleList):
+                    parent[int(child)] = w
+                else:
+                    setattr(parent, child, w)
+        names = seed_joint_and_lora_(m)
+        out["n_seeded"] = torch.tensor(len(names))
+        out["checksum"] = torch.tensor(checksum(m), dtype=torch.float64)
+        for mod in m.modules():
+            if isinstance(mod, LoraLinear):
+                mod.set_adapter(list(ADAPTERS))
+        call = lambda: m(inp["sample"], inp["t"], inp["enc"], added_time_ids=inp["ids"], return_dict=False)[0]  # noqa: E731
+        patch_mod.set_joint_attention_mask(m, JOINT_MASK)
+        patch_mod.set_joint_attention(m, True)
+        out["plain_peft"] = call()                          # unhacked peft forward: both adapters on every entry
+        patch_mod.hack_lora_forward(m)
+        for a, mk in MASKS.items():
+            patch_mod.set_patch_lora_mask(m, a, mk)
+        out["masked"] = call()
+        patch_mod.set_joint_attention(m, False)
+        out["masked_nojoint"] = call()
+        patch_mod.set_joint_attention(m, True)
+        for mod in m.modules():                             # single_lora branch of the loader (:598-599)
+            if isinstance(mod, LoraLinear):
+                mod.set_adapter(["xy_lora"])
+        patch_mod.set_patch_lora_mask(m, "xy_lora", [1, 1, 1, 1])
+        out["single_all_ones"] = call()
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "patch_lora.safetensors"))
+    print("patch_lora: %d seeded tensors; masked vs plain delta %.4f, masked vs nojoint %.4f, single %.4f" % (
+        len(names), (out["masked"] - out["plain_peft"]).abs().max(), (out["masked"] - out["masked_nojoint"]).abs().max(),
+        (out["single_all_ones"] - out["masked"]).abs().max()))
+
+
 def _run_pipeline_loop(pipe_mod, unet, sched_mod, image, lat0, px, frames, steps_n, gen_seed):
     """the reference `__call__` (output_type="latent") with stand-in CLIP / VAE; returns what the loop tests need"""
     from oracle.scheduler import SchedulerConfig
@@ -732,6 +844,14 @@ def main():
     install_stubs()
     sys.path.insert(0, REF)
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "patch_lora":
+        for m in ("models", "utils"):
+            _mod(m)
+        ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
+                             "models.unet_spatio_temporal_condition_controlnet")
+        _mod("patch")
+        load_ref("patch/utils.py", "patch.utils")
+        return gen_patch_lora(load_ref("patch/patch.py", "patch.patch"), ref_stock)
     if only in ("loop25", "loop25_c1", "unet_fullres", "unet_fullres_lk"):     # round-2 fixtures, one at a time
         for m in ("models", "utils"):
             _mod(m)
@@ -788,6 +908,7 @@ def main():
     patch_mod = load_ref("patch/patch.py", "patch.patch")
     sys.modules["patch"].patch = patch_mod
     gen_patch(patch_mod)
+    gen_patch_lora(patch_mod, ref_stock)
     uo = _mod("utils.optical_flow") if "utils" in sys.modules else None
     if uo is None:
         _mod("utils")

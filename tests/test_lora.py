@@ -1,0 +1,200 @@
+"""Masked LoRA: the reference's inference loader wraps the attention projections in peft LoRA
+layers, switches them to `lora_forward_hack` (patch/patch.py:57-92) and masks adapters per batch entry
+(utils/util.py:570-606).  Fixture tests/golden/patch_lora.safetensors = outputs of the reference's own UNet `forward` with
+its `patch` module and its vendored peft layer (models/lora_layer.py) - see make_goldens.py::gen_patch_lora."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from golden.lora_cases import ADAPTERS, ALPHA, JOINT_MASK, MASKS, RANK, lora_inputs, seed_joint_and_lora_
+
+WSEED = 7
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def _ck(m):
+    return float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return load_file(os.path.join(golden_dir, "patch_lora.safetensors"))
+
+
+def _oracle_base():
+    from oracle import unet as ou
+    o = ou.init_weights_(ou.UNetSpatioTemporalConditionControlNetModel(ou.TINY_CONFIG), WSEED + 9)
+    with torch.no_grad():
+        for p in o.parameters():
+            p.copy_(p.half().float())
+    return o
+
+
+def _call(m, i, dev=None):
+    mv = (lambda t: t.to(dev)) if dev else (lambda t: t)
+    with torch.no_grad():
+        return m(mv(i["sample"]), mv(i["t"]), mv(i["enc"]), added_time_ids=mv(i["ids"]), return_dict=False)[0]
+
+
+def test_oracle_masked_lora_vs_reference_golden(golden):
+    """pins oracle/lora.py + oracle/patch_hooks.apply_joint on the reference's own `lora_forward_hack` run"""
+    from oracle import lora as ol
+    from oracle import patch_hooks as oph
+    g = golden
+    o = _oracle_base()
+    assert abs(_ck(o) - g["checksum_base"].item()) <= 1e-9 * _ck(o)
+    oph.apply_joint(o, JOINT_MASK)                      # loader order: joint layers first, then the adapters (attn1n too)
+    ol.inject(o, ADAPTERS, RANK, ALPHA)
+    names = seed_joint_and_lora_(o)
+    assert len(names) == int(g["n_seeded"]) and abs(_ck(o) - g["checksum"].item()) <= 1e-9 * _ck(o)
+    i = lora_inputs()
+    assert _rel(_call(o, i), g["plain_peft"]) < 1e-4
+    ol.hack_lora_forward(o)
+    for a, mk in MASKS.items():
+        ol.set_patch_lora_mask(o, a, mk)
+    assert _rel(_call(o, i), g["masked"]) < 1e-4
+    for m in o.modules():
+        if hasattr(m, "enable_joint_attention"):
+            m.enable_joint_attention = False
+    assert _rel(_call(o, i), g["masked_nojoint"]) < 1e-4
+    for m in o.modules():
+        if hasattr(m, "enable_joint_attention"):
+            m.enable_joint_attention = True
+    ol.set_adapters(o, ["xy_lora"])
+    ol.set_patch_lora_mask(o, "xy_lora", [1, 1, 1, 1])
+    assert _rel(_call(o, i), g["single_all_ones"]) < 1e-4
+    assert _rel(g["masked"], g["plain_peft"]) > 5e-2     # the fixture's masks matter
+
+
+def _hip_model(golden, device="cpu"):
+    from lkgd_amd import lora, patch
+    from lkgd_amd import unet as pu
+    from oracle import unet as ou
+    m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    m.load_state_dict(_oracle_base().state_dict())
+    patch.apply_patch(m, flip=False, with_temporal_block=True, with_spatial_block=True)
+    patch.initialize_joint_layers(m)
+    for a in ADAPTERS:
+        lora.add_adapter(m, a, r=RANK, lora_alpha=ALPHA)
+    names = seed_joint_and_lora_(m)
+    assert len(names) == int(golden["n_seeded"]) and abs(_ck(m) - golden["checksum"].item()) <= 1e-9 * _ck(m)
+    lora.set_adapters(m, list(ADAPTERS))
+    patch.set_joint_attention_mask(m, JOINT_MASK)
+    return m
+
+
+def test_lora_wrappers_state_dict_names_and_plan(golden):
+    """host logic without a GPU: peft's parameter names, the suffix target rule, the per-entry plan of the loader's masks
+    (inverted on attn1n K / V AND seen through the partner permutation), merge arithmetic, loader key formats"""
+    from lkgd_amd import lora, patch
+    from lkgd_amd._lib import LkgdHipError
+    m = _hip_model(golden)
+    sd = m.state_dict()
+    k = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q"
+    assert f"{k}.base_layer.weight" in sd and f"{k}.lora_A.xy_lora.weight" in sd and f"{k}.lora_B.yx_lora.weight" in sd
+    assert "down_blocks.0.attentions.0.transformer_blocks.0.attn1n.to_out.0.lora_A.xy_lora.weight" in sd
+    assert not any("ff" in n and "lora" in n for n in sd)               # feed-forward Linears are not targets
+    assert sd[f"{k}.lora_A.xy_lora.weight"].shape == (RANK, 64)
+    # unmasked: one run over the whole batch with both adapters
+    plan = lora.entry_plan(m, 4, [1, 0, 3, 2])
+    blk = m.down_blocks[0].attentions[0].transformer_blocks[0]
+    assert plan.runs == [(0, 4)] and plan.adapters(blk.attn1.to_q, 0) == ADAPTERS
+    patch.hack_lora_forward(m)
+    with pytest.raises(LkgdHipError):
+        lora.entry_plan(m, 4, [1, 0, 3, 2])                              # hacked forward without masks: KeyError in the reference
+    for a, mk in MASKS.items():
+        patch.set_patch_lora_mask(m, a, mk)
+    assert bool((blk.attn1n.to_k.lora_mask["xy_lora"] == ~torch.tensor(MASKS["xy_lora"], dtype=torch.bool)).all())
+    assert bool((blk.attn1.to_k.lora_mask["xy_lora"] == torch.tensor(MASKS["xy_lora"], dtype=torch.bool)).all())
+    plan = lora.entry_plan(m, 4, [1, 0, 3, 2])
+    assert plan.runs == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    assert plan.adapters(blk.attn1.to_q, 0) == ("xy_lora",) and plan.adapters(blk.attn1.to_q, 1) == ("yx_lora",)
+    # attn1n K/V: inverted mask [0,1,0,1] for xy_lora, and OUR rows of entry 0 are consumed by entry 1 -> xy active on them
+    assert plan.adapters(blk.attn1n.to_k, 0, via_partner=True) == ("xy_lora",)
+    assert plan.adapters(blk.attn1n.to_q, 0) == ("xy_lora",)
+    # batch of 8 entries with 4-entry masks: two consecutive entries per mask entry
+    assert lora.entry_plan(m, 8, None).runs == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    with pytest.raises(LkgdHipError):
+        lora.entry_plan(m, 6, None)
+    # effective weight == base + scaling * B @ A
+    w = blk.attn1.to_q
+    exp = w.base_layer.weight.float() + (ALPHA / RANK) * w.lora_B["xy_lora"].weight.float() @ w.lora_A["xy_lora"].weight.float()
+    torch.testing.assert_close(w.effective_weight(("xy_lora",)), exp)
+    with pytest.raises(LkgdHipError):
+        lora.merge_lora(m)                                               # masked adapters are not one weight
+    patch.set_patch_lora_mask(m, "xy_lora", [1, 1, 1, 1])
+    lora.set_adapters(m, ["xy_lora"])
+    lora.merge_lora(m)
+    assert not lora.lora_layers(m) and isinstance(blk.attn1.to_q, torch.nn.Linear)
+    torch.testing.assert_close(blk.attn1.to_q.weight.float(), exp.half().float(), rtol=2e-3, atol=2e-3)
+    with pytest.raises(LkgdHipError):
+        lora.add_adapter(m, "bad", target_modules=["ff.net.2"])
+
+
+def test_load_lora_into_unet_key_formats(tmp_path, golden):
+    """diffusers' `lora_state_dict(dir)` + `load_lora_into_unet(...)` as the loader calls them (utils/util.py:572-576)"""
+    from safetensors.torch import save_file
+    from lkgd_amd import lora
+    from lkgd_amd import unet as pu
+    from oracle import unet as ou
+    m = pu.UNetSpatioTemporalConditionControlNetModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    g = torch.Generator().manual_seed(3)
+    mods = ["down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q",
+            "mid_block.attentions.0.temporal_transformer_blocks.0.attn2.to_out.0"]
+    sd = {}
+    for i, mod in enumerate(mods):
+        lin = m.get_submodule(mod)
+        sd[f"unet.{mod}.lora_A.weight"] = torch.randn(3 + i, lin.in_features, generator=g)
+        sd[f"unet.{mod}.lora_B.weight"] = torch.randn(lin.out_features, 3 + i, generator=g)
+    sd[f"unet.{mods[0]}.alpha"] = torch.tensor(6.0)
+    save_file(sd, str(tmp_path / "pytorch_lora_weights.safetensors"))
+    state, alphas = lora.lora_state_dict(str(tmp_path))
+    assert alphas == {f"unet.{mods[0]}.alpha": 6.0} and len(state) == 4
+    lora.load_lora_into_unet(state, alphas, unet=m, adapter_name="y_lora")
+    w0, w1 = m.get_submodule(mods[0]), m.get_submodule(mods[1])
+    assert w0.r["y_lora"] == 3 and w0.scaling["y_lora"] == 2.0 and w1.r["y_lora"] == 4 and w1.scaling["y_lora"] == 1.0
+    assert torch.equal(w0.lora_A["y_lora"].weight, sd[f"unet.{mods[0]}.lora_A.weight"])
+    assert [n for n, _ in lora.lora_layers(m)] == mods and w0.active_adapters == ["y_lora"]
+    lora.set_adapters(m, ["y_lora"], weights=[0.5])
+    assert w0.scaling["y_lora"] == 1.0
+    with pytest.raises(ValueError):
+        lora.load_lora_into_unet({"unet.nope.lora_A.weight": torch.zeros(2, 4), "unet.nope.lora_B.weight": torch.zeros(4, 2)},
+                                 None, unet=m, adapter_name="z")
+
+
+@pytest.mark.gpu
+def test_hip_masked_lora_vs_reference_golden(golden):
+    """the loader's sequence on the HIP path against the reference's outputs: plain peft forward (one variant), hacked
+    forward with per-entry masks (per-entry weight variants, one GEMM launch per entry run), joint attention off / on,
+    the single-LoRA all-ones branch, and `merge_lora` of that branch"""
+    from lkgd_amd import lora, patch
+    g = golden
+    m = _hip_model(g).half().to(DEV)
+    i = lora_inputs()
+    patch.set_joint_attention(m, True)
+    assert _rel(_call(m, i, DEV), g["plain_peft"]) < 1e-2
+    patch.hack_lora_forward(m)
+    for a, mk in MASKS.items():
+        patch.set_patch_lora_mask(m, a, mk)
+    got = _call(m, i, DEV)
+    r = _rel(got, g["masked"])
+    print(f"\nmasked LoRA + joint attention vs the reference: rel L2 {r:.3e}")
+    assert r < 1e-2 and (got.float().cpu() - g["masked"]).abs().max() < 5e-2
+    assert _rel(got, g["plain_peft"]) > 5e-2
+    patch.set_joint_attention(m, False)
+    assert _rel(_call(m, i, DEV), g["masked_nojoint"]) < 1e-2
+    patch.set_joint_attention(m, True)
+    lora.set_adapters(m, ["xy_lora"])
+    patch.set_patch_lora_mask(m, "xy_lora", [1, 1, 1, 1])
+    single = _call(m, i, DEV)
+    assert _rel(single, g["single_all_ones"]) < 1e-2
+    lora.merge_lora(m)
+    assert not lora.lora_layers(m)
+    assert _rel(_call(m, i, DEV), single) < 3e-3          # folded once into fp16 base weights vs folded per variant
