@@ -9,9 +9,12 @@ import torch
 from lkgd_amd import ops
 
 DEV = "cuda:0"
-if os.environ.get("ATTN_WAVES"):        # A/B knob: 4 or 8 waves (128 / 256 queries) per workgroup
+if os.environ.get("ATTN_WAVES"):        # A/B knob: 4, 8 or 16 waves (128 / 256 / 512 queries) per workgroup
     from lkgd_amd import _lib
     _lib.lib().lkgd_debug_set_attn_waves(int(os.environ["ATTN_WAVES"]))
+if os.environ.get("ATTN_KVB"):          # A/B knob: 64 or 128 keys staged per barrier
+    from lkgd_amd import _lib
+    _lib.lib().lkgd_debug_set_attn_kvb(int(os.environ["ATTN_KVB"]))
 
 
 def bench(fn, iters=5):
