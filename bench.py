@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--inference-steps", type=int, default=25)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet config (plumbing checks only; not a valid number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed) VAE encode / decode measurement")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--lk", action="store_true",
                     help="configs[2]: the LKGD UNet (UNetSpatioTemporalConditionModel) with domain / flow features fused into the "
@@ -122,6 +123,38 @@ def cpu_baseline(args):
             "sample": f"oracle fp32 (torch eager), one UNet forward of the real-shaped SVD UNet at CFG-batch 2 x 2 frames "
                       f"x 32x32 latent (half of config 1's geometry, {tflop_sample:.2f} TFLOP) in {dt:.1f} s = {tflops:.3f} TFLOP/s on {cores} "
                       f"threads (os.cpu_count={os.cpu_count()}); model build {t_build:.0f} s not counted"}
+
+
+def vae_stages(dev, args, latents, loop_s_per_clip):
+    """outside the timed region: the clip-level stages either side of the loop on the HIP path (lkgd_amd/vae.py, random-init
+    SVD VAE shapes) - encode of the conditioning image, temporal decode of the clip's denoised latents in one chunk - and
+    the end-to-end videos/s they imply next to the loop-only metric"""
+    from lkgd_amd import unet as pu
+    from lkgd_amd import vae as pv
+    with torch.device("meta"):
+        v = pv.AutoencoderKLTemporalDecoder()
+    v = v.to(torch.float16).to_empty(device=dev)
+    pu.init_synthetic_weights_(v, seed=2)
+    img = torch.rand(1, 3, args.height, args.width, generator=torch.Generator().manual_seed(5)).to(dev) * 2 - 1
+    z = (latents[0].float() / v.config.scaling_factor).clamp(-30, 30).half()          # [F, 4, h, w]
+
+    def timed(fn, reps=2):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, r
+    t_enc, _ = timed(lambda: v.encode(img).latent_dist.mode())
+    t_dec, frames = timed(lambda: v.decode(z, num_frames=args.frames).sample)
+    total = loop_s_per_clip + t_enc + t_dec
+    return {"vae_encode_ms": round(t_enc * 1e3, 2), "vae_decode_ms": round(t_dec * 1e3, 2),
+            "decode_chunk_size": args.frames, "decoded": list(frames.shape),
+            "finite": bool(torch.isfinite(frames.float()).all().item()),
+            "videos_per_s": round(1.0 / total, 4), "frames_per_s": round(args.frames / total, 4),
+            "note": "loop + VAE encode + temporal VAE decode of one clip (CLIP image encoder not included); untimed extras, "
+                    "the headline value is the loop alone"}
 
 
 def self_launch(args) -> int:
@@ -300,6 +333,9 @@ def main():
                     "launches_timed": f"every GEMM launch of {clips_sampled} of the {args.steps} timed clips" + (
                         "" if not distributed else f", {sampled} of {args.inference_steps} Euler steps each")}
 
+    e2e = None
+    if rank == 0 and world == 1 and not args.tiny and not args.no_vae:
+        e2e = vae_stages(dev, args, out, dt / args.steps / nclips)
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -320,7 +356,7 @@ def main():
                                    + (" [TINY UNET - INVALID]" if args.tiny else ""),
                        "unet": "random-init SVD shapes (320,640,1280,1280), heads (5,10,20,20), 1.52 B params",
                        "parallelism": "single GPU" if world == 1 else f"cfg x frame shards over {world} GPUs"},
-            "finite_output": finite, "rccl_ranks": comm_ranks,
+            "finite_output": finite, "rccl_ranks": comm_ranks, "end_to_end": e2e,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -87,6 +87,9 @@ typedef struct lkgd_gemm_desc {
   int32_t ldr1, ldr2, ldc;
   float s_acc, r1, r2;
   int32_t geglu;           /* 0 = off, 32 or 80 = GEGLU interleave width (see above) */
+  int32_t pad_off;         /* CONV3X3: 0 = symmetric zero padding 1 (every UNet convolution); 1 = no padding at the top / left
+                              and one zero row / column at the bottom / right - F.pad(x, (0,1,0,1)) + stride-2 conv with
+                              padding 0, the VAE encoder's Downsample2D [EXT diffusers downsampling.py] */
   void* workspace;         /* optional fp32 scratch for split-K partial sums (NULL = never split).  Few-row problems */
   int64_t workspace_bytes; /* (M < 8192: the 18x32 / 9x16 levels, or a frame-sharded rank's slice) fill a fraction of
                               the CUs with 128x128 tiles; K is then cut into up to 16 slices whose fp32 partial tiles
@@ -247,6 +250,21 @@ int lkgd_conv1d_reflect(const float* in, float* out, int64_t planes, int32_t H, 
                         int32_t ntaps, int32_t axis, lkgd_stream_t stream);
 int lkgd_resize_bicubic_ac(const float* in, int64_t planes, int32_t H, int32_t W, float* out, int32_t Ho, int32_t Wo,
                            lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 12. Clip-level VAE stages (boundary stages either side of the loop): the two ops of
+ *     AutoencoderKLTemporalDecoder [EXT diffusers 0.27.2; called at pipeline_stable_video_diffusion_trans.py:205-226,
+ *     :256-283] that the GEMM / GroupNorm entry points above do not cover.
+ *     `lkgd_softmax_rows`: y[r, :cols] = softmax(x[r, :cols]) per row, fp16 in / out, fp32 inside; cols % 8 == 0,
+ *       cols <= 16384.  Replaces the softmax inside F.scaled_dot_product_attention of the single-head (head_dim 512)
+ *       mid-block attention, whose QK^T and PV products run through lkgd_gemm_f16.
+ *     `lkgd_time_conv_out`: out[b,f,co,p] = bias[co] + sum_{kt,ci} w[co][ci][kt] * x[(b, f+kt-1, p), ci], 3 channels,
+ *       zero beyond the chunk's frames; input channels-last tokens [nbatch*F*HW, ld >= 4], output NCHW frames
+ *       [nbatch*F, 3, HW] fp32 or fp16.  Replaces TemporalDecoder.time_conv_out (Conv3d (3,1,1)) + the layout change.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_softmax_rows(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t cols, lkgd_stream_t stream);
+int lkgd_time_conv_out(const void* tokens, int32_t ld, const float* w, const float* bias, void* out, int32_t out_is_f32,
+                       int64_t nbatch, int32_t F, int32_t HW, lkgd_stream_t stream);
 
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);

@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("rb_c0", C.c_int32),
         ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("ldc", C.c_int32),
         ("s_acc", C.c_float), ("r1", C.c_float), ("r2", C.c_float),
-        ("geglu", C.c_int32),
+        ("geglu", C.c_int32), ("pad_off", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
@@ -80,6 +80,8 @@ SYMBOLS = {
     "lkgd_conv3x3_small": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
     "lkgd_conv1d_reflect": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp]),
     "lkgd_resize_bicubic_ac": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "lkgd_softmax_rows": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
+    "lkgd_time_conv_out": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "lkgd_version": (C.c_char_p, []),
 }
 

@@ -120,6 +120,32 @@ class ControlNetSDVModel(_UNetBase):
         self.controlnet_mid_block = zero_conv(boc[-1])
         self._cond_cache = None
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, subfolder: Optional[str] = None, torch_dtype=None,
+                        variant: Optional[str] = None, **_ignored):
+        from .loading import build_from_pretrained
+        return build_from_pretrained(cls, UNetConfig, pretrained_model_name_or_path, subfolder, torch_dtype, variant,
+                                     conditioning_channels=3, conditioning_embedding_out_channels=(16, 32, 96, 256))
+
+    def save_pretrained(self, save_directory: str, variant: Optional[str] = None, **_ignored):
+        from .loading import save_pretrained
+        save_pretrained(self, save_directory, dict(self.config.__dict__), type(self).__name__, variant)
+
+    @classmethod
+    def from_unet(cls, unet, controlnet_conditioning_channel_order: str = "rgb",
+                  conditioning_embedding_out_channels: Tuple[int, ...] = (16, 32, 96, 256),
+                  load_weights_from_unet: bool = True, conditioning_channels: int = 3):
+        """controlnet_sdv.py:581-637: the UNet's config, and (optionally) its conv_in / embeddings / down blocks / mid block"""
+        cfg = UNetConfig(**{k: v for k, v in unet.config.__dict__.items() if k in UNetConfig.__dataclass_fields__})
+        c = cls(cfg, conditioning_channels=conditioning_channels,
+                conditioning_embedding_out_channels=conditioning_embedding_out_channels)
+        c = c.to(device=unet.device, dtype=unet.dtype)
+        if load_weights_from_unet:
+            for name in ("conv_in", "time_embedding", "add_embedding", "down_blocks", "mid_block"):
+                getattr(c, name).load_state_dict(getattr(unet, name).state_dict())
+            c.invalidate()
+        return c
+
     def _pack_extra(self, pk):
         self.controlnet_cond_embedding.pack()
         pk.zero = [(pack_linear(m.weight.detach().reshape(m.out_channels, m.in_channels)), _f32(m.bias))

@@ -297,9 +297,11 @@ static int check_desc(const lkgd_gemm_desc* d) {
       if (d->stride != 1 && d->stride != 2) return LKGD_E_SHAPE;
       if (d->ups != 0 && d->ups != 1) return LKGD_E_SHAPE;
       if (d->M % (d->Hout * d->Wout)) return LKGD_E_SHAPE;
-      // pad-1 output size must match: Hout = floor((Hv + 2 - 3)/stride) + 1
-      if (d->Hout != (((d->Hin << d->ups) - 1) / d->stride) + 1) return LKGD_E_SHAPE;
-      if (d->Wout != (((d->Win << d->ups) - 1) / d->stride) + 1) return LKGD_E_SHAPE;
+      if (d->pad_off != 0 && d->pad_off != 1) return LKGD_E_SHAPE;
+      // output size must match: pad 1 on every side: floor((Hv + 2 - 3)/stride) + 1;  pad_off (0 top/left, 1 bottom/right):
+      // floor((Hv + 1 - 3)/stride) + 1
+      if (d->Hout != (((d->Hin << d->ups) - 1 - d->pad_off) / d->stride) + 1) return LKGD_E_SHAPE;
+      if (d->Wout != (((d->Win << d->ups) - 1 - d->pad_off) / d->stride) + 1) return LKGD_E_SHAPE;
       break;
     case LKGD_A_TCONV3:
       if (d->Cin <= 0 || d->Cin % BK || d->K != 3 * d->Cin) return LKGD_E_SHAPE;
@@ -307,7 +309,7 @@ static int check_desc(const lkgd_gemm_desc* d) {
       if (d->M % (d->Floc * d->HW)) return LKGD_E_SHAPE;
       break;
     case LKGD_A_CONV3X3_C8:
-      if (d->Cin != 8 || d->K != 128 || d->lda0 != 8 || d->stride != 1 || d->ups != 0) return LKGD_E_SHAPE;
+      if (d->Cin != 8 || d->K != 128 || d->lda0 != 8 || d->stride != 1 || d->ups != 0 || d->pad_off != 0) return LKGD_E_SHAPE;
       if (d->Hout != d->Hin || d->Wout != d->Win || d->M % (d->Hout * d->Wout)) return LKGD_E_SHAPE;
       break;
     default:

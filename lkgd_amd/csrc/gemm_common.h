@@ -64,8 +64,8 @@ __device__ __forceinline__ ARow a_row(const lkgd_gemm_desc& p, int m) {
       int n = m / hw, rem = m - n * hw;
       int y = rem / p.Wout, x = rem - y * p.Wout;
       r.base = (long long)n * p.Hin * p.Win;
-      r.y = y * p.stride - 1;
-      r.x = x * p.stride - 1;
+      r.y = y * p.stride - 1 + p.pad_off;
+      r.x = x * p.stride - 1 + p.pad_off;
     } else if (mode == LKGD_A_TCONV3) {
       int bf = m / p.HW;                 // b*Floc + fl
       int b = bf / p.Floc;
@@ -188,7 +188,7 @@ __device__ __forceinline__ RowD lean_row(const lkgd_gemm_desc& p, int m, float r
       const int n = fast_div(m, hw, rcp0), rem = m - n * hw;
       const int y = fast_div(rem, p.Wout, rcp1), x = rem - y * p.Wout;
       r.base = n * p.Hin * p.Win;
-      r.yx = ((y * p.stride - 1) & 0xffff) | ((x * p.stride - 1) << 16);
+      r.yx = ((y * p.stride - 1 + p.pad_off) & 0xffff) | ((x * p.stride - 1 + p.pad_off) << 16);
     } else if (MODE == LKGD_A_TCONV3) {
       const int bf = fast_div(m, p.HW, rcp0);               // b*Floc + fl
       const int b = fast_div(bf, p.Floc, rcp1);

@@ -107,8 +107,9 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
         d.csplit = csplit if csplit is not None else K
     else:
         d.csplit = csplit if csplit is not None else Cin
-    if conv is not None:
-        d.Hout, d.Wout, d.Hin, d.Win, d.stride, d.ups = conv
+    if conv is not None:          # (Hout, Wout, Hin, Win, stride, ups[, pad_off])
+        d.Hout, d.Wout, d.Hin, d.Win, d.stride, d.ups = conv[:6]
+        d.pad_off = conv[6] if len(conv) > 6 else 0
     if tconv is not None:      # (F, HW) or (F, HW, Floc, f_off) under frame sharding
         d.F, d.HW = tconv[0], tconv[1]
         d.Floc, d.f_off = (tconv[2], tconv[3]) if len(tconv) == 4 else (tconv[0], 0)
@@ -351,6 +352,25 @@ def conv3x3_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     out = torch.empty(nimg * Hout * Wout, cout, dtype=torch.float16, device=x.device)
     check(_L().lkgd_conv3x3_small(x.data_ptr(), cin, _ld(x), w.data_ptr(), _ptr(bias), out.data_ptr(), cout,
                                         _ld(out), nimg, Hin, Win, stride, int(silu), _stream()), "lkgd_conv3x3_small")
+    return out
+
+
+def softmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """row softmax of an fp16 score matrix (include/lkgd_hip.h section 12); in place when out is None"""
+    _req(x, torch.float16, "x")
+    out = x if out is None else out
+    check(_L().lkgd_softmax_rows(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), x.shape[0], x.shape[1], _stream()),
+          "lkgd_softmax_rows")
+    return out
+
+
+def time_conv_out(tokens: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, nbatch: int, F: int, H: int, W: int,
+                  dtype=torch.float32) -> torch.Tensor:
+    """Conv3d (3,1,1) over the frames on 3 channels + channels-last -> NCHW (section 12); w fp32 [3, 3, 3] = (co, ci, kt)"""
+    _req(tokens, torch.float16, "tokens"); _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias")
+    out = torch.empty(nbatch * F, 3, H, W, dtype=dtype, device=tokens.device)
+    check(_L().lkgd_time_conv_out(tokens.data_ptr(), _ld(tokens), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                  int(dtype == torch.float32), nbatch, F, H * W, _stream()), "lkgd_time_conv_out")
     return out
 
 

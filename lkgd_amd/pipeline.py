@@ -74,6 +74,70 @@ class StableVideoDiffusionPipeline:
                                      # individual GEMM launches with events, which a graph replay cannot expose
         self._graph = None
 
+    # ---- loading (DiffusionPipeline.from_pretrained [EXT]; call sites run_models/run_inference_svd.py:166-168,
+    #      utils/util.py:536) --------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, torch_dtype=torch.float16, variant: Optional[str] = None,
+                        unet=None, vae=None, image_encoder=None, feature_extractor=None, scheduler=None, controlnet=None,
+                        unet_class=None, device: Optional[str] = "cuda", **_ignored):
+        """a local diffusers pipeline directory (``unet/ vae/ image_encoder/ feature_extractor/ scheduler/``).  The UNet,
+        the VAE and the scheduler are lkgd_amd's own classes; CLIP (`image_encoder`, `feature_extractor`) is a boundary
+        stage and comes from `transformers` when that package is importable and the folders exist.  Components passed
+        as keywords are used as given (``unet=...`` as utils/util.py:607-616 does).  hub / offload keywords are accepted
+        and ignored (``low_cpu_mem_usage``, ``device_map``, ``local_files_only`` ...)."""
+        import os
+        from .unet import UNetSpatioTemporalConditionControlNetModel
+        from .vae import AutoencoderKLTemporalDecoder
+        root = pretrained_model_name_or_path
+        if not os.path.isdir(root):
+            raise OSError(f"{root} is not a local pipeline directory (there is no hub access)")
+
+        def has(sub, f):
+            return os.path.exists(os.path.join(root, sub, f))
+        if unet is None:
+            unet = (unet_class or UNetSpatioTemporalConditionControlNetModel).from_pretrained(
+                root, subfolder="unet", torch_dtype=torch_dtype, variant=variant)
+        if vae is None and has("vae", "config.json"):
+            vae = AutoencoderKLTemporalDecoder.from_pretrained(root, subfolder="vae", torch_dtype=torch_dtype, variant=variant)
+        if scheduler is None and has("scheduler", "scheduler_config.json"):
+            scheduler = EulerDiscreteScheduler.from_pretrained(root, subfolder="scheduler")
+        if image_encoder is None and has("image_encoder", "config.json"):
+            try:
+                from transformers import CLIPVisionModelWithProjection
+            except ImportError as e:
+                raise LkgdHipError("image_encoder/ needs `transformers` (CLIPVisionModelWithProjection); pass "
+                                   "`image_embeddings=` to __call__ instead") from e
+            image_encoder = CLIPVisionModelWithProjection.from_pretrained(os.path.join(root, "image_encoder"),
+                                                                          dtype=torch_dtype)
+        if feature_extractor is None and has("feature_extractor", "preprocessor_config.json"):
+            from transformers import CLIPImageProcessor
+            feature_extractor = CLIPImageProcessor.from_pretrained(os.path.join(root, "feature_extractor"))
+        pipe = cls(vae=vae, image_encoder=image_encoder, unet=unet, scheduler=scheduler,
+                   feature_extractor=feature_extractor, controlnet=controlnet)
+        return pipe.to(device) if device is not None else pipe
+
+    def to(self, device=None, dtype=None):
+        """``DiffusionPipeline.to`` [EXT]: every module component to the device (the HIP models run on cuda only)"""
+        for name in ("unet", "vae", "image_encoder", "controlnet"):
+            m = getattr(self, name, None)
+            if m is not None and hasattr(m, "to"):
+                m = m.to(device=device, dtype=dtype) if dtype is not None else m.to(device)
+                setattr(self, name, m)
+        return self
+
+    def save_pretrained(self, save_directory: str, **kw):
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        index = {"_class_name": "StableVideoDiffusionPipeline", "_lkgd_amd": True}
+        for name in ("unet", "vae", "image_encoder", "feature_extractor", "scheduler"):
+            m = getattr(self, name, None)
+            if m is not None and hasattr(m, "save_pretrained"):
+                m.save_pretrained(os.path.join(save_directory, name))
+                index[name] = [type(m).__module__.split(".")[0], type(m).__name__]
+        with open(os.path.join(save_directory, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2)
+
     # ---- reference helpers -------------------------------------------------------------------------------------
     @property
     def guidance_scale(self):

@@ -74,6 +74,24 @@ class EulerDiscreteScheduler:
                    sigma_min=0.002, sigma_max=700.0, timestep_spacing="leading", timestep_type="continuous",
                    steps_offset=1)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, subfolder: Optional[str] = None, **_ignored):
+        """``SchedulerMixin.from_pretrained`` [EXT]: ``scheduler_config.json`` of a local pipeline directory"""
+        from .loading import load_config
+        import inspect
+        raw = load_config(pretrained_model_name_or_path, subfolder, "scheduler_config.json")
+        known = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        return cls(**{k: v for k, v in raw.items() if k in known})
+
+    def save_pretrained(self, save_directory: str, **_ignored):
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {"_class_name": "EulerDiscreteScheduler"}
+        cfg.update({k: v for k, v in vars(self.config).items()})
+        with open(os.path.join(save_directory, "scheduler_config.json"), "w") as fh:
+            json.dump(cfg, fh, indent=2, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+
     # ---- host tables ------------------------------------------------------------------------------------------
     def _train_sigmas(self) -> np.ndarray:
         ac = self.alphas_cumprod.numpy()

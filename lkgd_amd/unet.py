@@ -980,6 +980,24 @@ class _UNetBase(nn.Module):
         pass
 
     # ---- reference API surface -----------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, subfolder: Optional[str] = None, torch_dtype=None,
+                        variant: Optional[str] = None, **_ignored):
+        """``ModelMixin.from_pretrained`` [EXT] for a local diffusers directory (``unet/config.json`` + safetensors), as
+        /root/reference/utils/util.py:607 / run_inference_svd.py:164 call it; hub / cache / device-map keywords are
+        accepted and ignored"""
+        from .loading import build_from_pretrained
+        return build_from_pretrained(cls, UNetConfig, pretrained_model_name_or_path, subfolder, torch_dtype, variant)
+
+    def save_pretrained(self, save_directory: str, variant: Optional[str] = None, **_ignored):
+        from .loading import save_pretrained
+        save_pretrained(self, save_directory, dict(self.config.__dict__), type(self).__name__, variant)
+
+    def set_adapters(self, adapter_names, weights=None):
+        """``unet.set_adapters`` [EXT PeftAdapterMixin], /root/reference/utils/util.py:596"""
+        from . import lora
+        lora.set_adapters(self, adapter_names, weights)
+
     @property
     def dtype(self):
         return self.conv_in.weight.dtype
