@@ -118,8 +118,14 @@ def cpu_baseline(args):
         return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "tiny config (invalid)"}
     tflops = tflop_sample / dt
     fps = args.frames / (args.inference_steps * UNET_TFLOP_C2 / tflops)
+    full = None      # the ONE full C2 forward of the same oracle timed on a GPU box's host (tools/cpu_full_forward.py, committed log)
+    try:
+        with open(os.path.join(REPO, "profiles", "r02_cpu_full_forward.json")) as f:
+            full = json.load(f)
+    except (OSError, ValueError):
+        pass
     return {"value": round(fps, 6), "unit": "frames/s (C2-equivalent, extrapolated by algorithmic FLOPs)",
-            "cores": cores, "kind": "port",
+            "cores": cores, "kind": "port", "full_forward_measured": full,
             "sample": f"oracle fp32 (torch eager), one UNet forward of the real-shaped SVD UNet at CFG-batch 2 x 2 frames "
                       f"x 32x32 latent (half of config 1's geometry, {tflop_sample:.2f} TFLOP) in {dt:.1f} s = {tflops:.3f} TFLOP/s on {cores} "
                       f"threads (os.cpu_count={os.cpu_count()}); model build {t_build:.0f} s not counted"}
@@ -228,8 +234,6 @@ def main():
     pipe = StableVideoDiffusionPipeline(unet=unet)
     dom = flow = None
     if args.lk:
-        if distributed:
-            raise SystemExit("--lk is a single-GPU option")
         dom = torch.randn(1, 1, 1000, generator=torch.Generator().manual_seed(12348)).half().to(dev)
         flow = torch.randn(1, 1, 1000, generator=torch.Generator().manual_seed(12349)).half().to(dev)
     lat0, img, emb, ids = synthetic_inputs(dev, args.frames, h, w)
@@ -254,8 +258,6 @@ def main():
         ids = ids[:1].repeat(4, 1)
     ctrl_cond = None
     if args.controlnet:
-        if distributed:
-            raise SystemExit("--controlnet is a single-GPU option")
         from lkgd_amd import controlnet as pc
         from lkgd_amd import unet as pu
         with torch.device("meta"):
@@ -274,7 +276,8 @@ def main():
         runner = DistDenoiser(pipe, world, rank, args.frames)
 
         def one_clip():
-            return runner.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0)
+            return runner.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0,
+                                  domain_features=dom, flow_features=flow, controlnet_condition=ctrl_cond)
     else:
         def one_clip():
             return pipe.denoise((lat0 * sigma0).half(), img, emb, ids, args.inference_steps, 1.0, 3.0,

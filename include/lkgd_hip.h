@@ -266,6 +266,15 @@ int lkgd_softmax_rows(const void* x, int32_t ldx, void* y, int32_t ldy, int64_t 
 int lkgd_time_conv_out(const void* tokens, int32_t ld, const float* w, const float* bias, void* out, int32_t out_is_f32,
                        int64_t nbatch, int32_t F, int32_t HW, lkgd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * 13. Front end of the domain / flow ViT encoders (train_models/train_svd_lora.py:1455-1466):
+ *     `F.interpolate(images, size=[S,S], mode="bilinear")` (align_corners=False) fused with the P x P patch unfold of timm's
+ *     PatchEmbed convolution [EXT]: out[(n, py, px), c*P*P + ky*P + kx] = resized[n, c, py*P+ky, px*P+kx], fp16
+ *     [nimg*(S/P)^2, C*P*P] = the A operand of the patch-embedding GEMM (weight [D, C, P, P] flattened).  in: fp32 NCHW.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_vit_patchify(const float* in, int64_t nimg, int32_t C, int32_t H, int32_t W, void* out, int32_t S, int32_t P,
+                      lkgd_stream_t stream);
+
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
 

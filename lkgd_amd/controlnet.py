@@ -169,10 +169,12 @@ class ControlNetSDVModel(_UNetBase):
 
     @torch.no_grad()
     def forward_tokens(self, tokens: torch.Tensor, B: int, F: int, H: int, W: int, timestep, encoder_hidden_states,
-                       added_time_ids, controlnet_cond=None, conditioning_scale: float = 1.0):
-        """channels-last entry: input tokens [B*F*H*W, 8] -> (list of 12 residual token matrices, mid residual tokens)"""
+                       added_time_ids, controlnet_cond=None, conditioning_scale: float = 1.0, shard=None):
+        """channels-last entry: input tokens [B*F*H*W, 8] -> (list of 12 residual token matrices, mid residual tokens).
+        Under frame / CFG sharding (``shard``, lkgd_amd/dist_run.py) B, F, the tokens and ``controlnet_cond`` are the
+        rank's LOCAL batch entries / frames; the encoder's temporal ops exchange exactly as the UNet's do."""
         self.prepare()
-        ctx = Ctx(B, F, H, W, self.device, None)
+        ctx = Ctx(B, F, H, W, self.device, shard)
         pk = self._pk
         self._time_embed(ctx, timestep, added_time_ids)
         self._cross_tables(ctx, encoder_hidden_states)

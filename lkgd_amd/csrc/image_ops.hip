@@ -104,3 +104,45 @@ extern "C" int lkgd_resize_bicubic_ac(const float* in, int64_t planes, int32_t H
                      in, (long long)planes, H, W, out, Ho, Wo, sy, sx);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ViT front end of the domain / flow encoders (include/lkgd_hip.h section 13): F.interpolate(mode="bilinear",
+// align_corners=False) to S x S fused with the P x P patch unfold of the patch-embedding convolution - the resized image
+// never exists; out[(n, py, px), c*P*P + ky*P + kx] fp16 is the A operand of the patch-embedding GEMM.
+__global__ void vit_patchify_kernel(const float* __restrict__ in, int C, int H, int W, half_t* __restrict__ out, int S, int P,
+                                    float sy, float sx, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int K = C * P * P, g = S / P;
+  const long long row = i / K;
+  const int k = (int)(i - row * K);
+  const int c = k / (P * P), kk = k - c * P * P, ky = kk / P, kx = kk - ky * P;
+  const long long n = row / (g * g);
+  const int pr = (int)(row - n * g * g), py = pr / g, px = pr - py * g;
+  const int y = py * P + ky, x = px * P + kx;
+  // PyTorch's area_pixel_compute_source_index(scale, dst, align_corners=False, cubic=False): max(scale*(dst+0.5)-0.5, 0)
+  float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  int y0 = (int)fy, x0 = (int)fx;
+  y0 = y0 > H - 1 ? H - 1 : y0;
+  x0 = x0 > W - 1 ? W - 1 : x0;
+  const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float* b = in + (n * C + c) * (long long)H * W;
+  const float v = (1.f - ly) * ((1.f - lx) * b[(long long)y0 * W + x0] + lx * b[(long long)y0 * W + x1]) +
+                  ly * ((1.f - lx) * b[(long long)y1 * W + x0] + lx * b[(long long)y1 * W + x1]);
+  out[i] = (half_t)v;
+}
+
+extern "C" int lkgd_vit_patchify(const float* in, int64_t nimg, int32_t C, int32_t H, int32_t W, void* out, int32_t S,
+                                 int32_t P, lkgd_stream_t stream) {
+  if (!in || !out) return LKGD_E_NULL;
+  if (nimg <= 0 || C <= 0 || H <= 0 || W <= 0 || S <= 0 || P <= 0 || S % P) return LKGD_E_SHAPE;
+  const long long total = (long long)nimg * S * S * C;
+  const long long nblk = (total + 255) / 256;
+  if (nblk > 0x7fffffffLL) return LKGD_E_SHAPE;
+  hipLaunchKernelGGL(vit_patchify_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, in, C, H, W, (half_t*)out, S,
+                     P, (float)H / (float)S, (float)W / (float)S, total);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}

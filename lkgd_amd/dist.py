@@ -78,6 +78,9 @@ def make_plan(world: int, rank: int, num_frames: int, cfg: bool) -> ShardPlan:
     return ShardPlan(world, rank, cfg_groups, shards, ci, si, splits, sum(splits[:si]), num_frames)
 
 
+_HALO_ALLGATHER = __import__("os").environ.get("LKGD_HALO_ALLGATHER", "0") == "1"
+
+
 def _backend(group) -> str:
     return dist.get_backend(group)
 
@@ -136,24 +139,57 @@ def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Ten
 def exchange_halo(buf: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
     """buf [f_local + 2, ...] with the rank's own frames already in slots 1..f_local: fills slot 0 with the previous
     shard's last frame and slot f_local + 1 with the next shard's first one.  At the ends of the clip the slot is left as
-    the caller allocated it (zeros = the Conv3d's zero padding).  One all-gather of two boundary frames per rank."""
+    the caller allocated it (zeros = the Conv3d's zero padding).
+
+    Neighbour-only exchange: each rank sends its first frame to shard i-1 and its last frame to shard i+1 and receives the
+    two it needs (``batch_isend_irecv`` - point-to-point over the one xGMI link to each neighbour), i.e. 2 frames in, 2
+    frames out per rank whatever the shard count; an all-gather of boundary frames would deliver 2(k-1) frames to every
+    rank, 6 of which a rank of 8 (k = 4) throws away.  LKGD_HALO_ALLGATHER=1 keeps that form as an A/B knob."""
     k, fl, si = plan.frame_shards, plan.f_local, plan.shard_index
     if k == 1:
         return buf
     if buf.shape[0] != fl + 2 or not buf.is_contiguous():
         raise ValueError("halo buffer must be a contiguous [f_local + 2, ...] tensor")
     frame = tuple(buf.shape[1:])
-    send = torch.empty((2,) + frame, dtype=buf.dtype, device=buf.device)
-    got = torch.empty((2 * k,) + frame, dtype=buf.dtype, device=buf.device)
+    if _HALO_ALLGATHER:
+        send = torch.empty((2,) + frame, dtype=buf.dtype, device=buf.device)
+        got = torch.empty((2 * k,) + frame, dtype=buf.dtype, device=buf.device)
+
+        def step():
+            send[0].copy_(buf[1])
+            send[1].copy_(buf[fl])
+            all_gather_into(got, send, group)
+            if si > 0:
+                buf[0].copy_(got[2 * (si - 1) + 1])
+            if si < k - 1:
+                buf[fl + 1].copy_(got[2 * (si + 1)])
+        _step(step)
+        return buf
+    ranks = plan.frame_group_ranks()                      # global ranks of the shards of this CFG half
+    prev_r = ranks[si - 1] if si > 0 else None
+    next_r = ranks[si + 1] if si < k - 1 else None
+    direct = _backend(group) == "nccl" or not buf.is_cuda     # gloo with device tensors: staged through host memory
 
     def step():
-        send[0].copy_(buf[1])
-        send[1].copy_(buf[fl])
-        all_gather_into(got, send, group)
-        if si > 0:
-            buf[0].copy_(got[2 * (si - 1) + 1])
-        if si < k - 1:
-            buf[fl + 1].copy_(got[2 * (si + 1)])
+        first, last, lo, hi = buf[1], buf[fl], buf[0], buf[fl + 1]
+        if not direct:
+            first, last = first.cpu(), last.cpu()
+            lo, hi = torch.empty_like(first), torch.empty_like(first)
+        ops_ = []
+        # the same order on both sides of a link: every rank posts [to prev, from prev, to next, from next]
+        if prev_r is not None:
+            ops_.append(dist.P2POp(dist.isend, first, prev_r, group))
+            ops_.append(dist.P2POp(dist.irecv, lo, prev_r, group))
+        if next_r is not None:
+            ops_.append(dist.P2POp(dist.isend, last, next_r, group))
+            ops_.append(dist.P2POp(dist.irecv, hi, next_r, group))
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+        if not direct:
+            if prev_r is not None:
+                buf[0].copy_(lo)
+            if next_r is not None:
+                buf[fl + 1].copy_(hi)
     _step(step)
     return buf
 

@@ -2,7 +2,7 @@
 
 Exchange points per UNet forward on a rank (frame_shards > 1 only):
   * each temporal GroupNorm  : all-reduce of [1,32,2] fp32 sums                            (22 blocks x 2)
-  * each temporal Conv3d     : all-gather of every rank's two boundary frames [2,HW,C]     (22 blocks x 2)
+  * each temporal Conv3d     : neighbour send/recv of the two boundary frames [HW,C] each   (22 blocks x 2)
   * each temporal attention  : all-gather of the normalised hidden states [F,HW,C]; K|V projected locally (16 blocks)
 and once per step, over ALL ranks, the all-gather of the noise prediction [cfg*F*HW, 4] (1 MB) before the replicated
 CFG-combine + Euler update.  With 2 GPUs (pure CFG-parallel) only the last exchange exists.
@@ -80,7 +80,13 @@ class DistDenoiser:
     def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, image_embeddings: torch.Tensor,
                 added_time_ids: torch.Tensor, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
                 max_guidance_scale: float = 3.0, domain_features: Optional[torch.Tensor] = None,
-                flow_features: Optional[torch.Tensor] = None) -> torch.Tensor:
+                flow_features: Optional[torch.Tensor] = None, controlnet_condition: Optional[torch.Tensor] = None,
+                controlnet_cond_scale: float = 1.0) -> torch.Tensor:
+        """``pipeline.denoise`` over the ranks.  ``domain_features`` / ``flow_features`` (the LKGD UNet): the fuse is
+        replicated (2 MFLOP) and every rank holds the fused embedding of BOTH CFG halves.  ``controlnet_condition``
+        [cfg, F, 3, 8h, 8w] (pipeline_stable_video_diffusion_controlnet.py:582-607): every rank embeds the condition frames of
+        ITS slice once per clip and runs the ControlNet-SVD encoder on its tokens before the UNet; the residuals are local
+        token matrices, so nothing new crosses the links beyond the encoder's own temporal exchanges."""
         pipe, plan = self.pipe, self.plan
         unet, sch = pipe.unet, pipe.scheduler
         dev = unet.device
@@ -122,6 +128,23 @@ class DistDenoiser:
         else:
             tok_local = torch.empty(cfg * fl * HW, 8, dtype=torch.float16, device=dev)
             pick = (tok_local.reshape(cfg, fl, HW, 8), tok.reshape(cfg, F, HW, 8)[:, f0:f0 + fl])
+        ctrl_local = None
+        if controlnet_condition is not None:
+            if getattr(pipe, "controlnet", None) is None:
+                raise LkgdHipError("controlnet_condition given but the pipeline has no controlnet")
+            if controlnet_condition.shape[0] != cfg or controlnet_condition.shape[1] != F:
+                raise ValueError("controlnet_condition must be [cfg, frames, 3, 8h, 8w] (uncond first)")
+            cc = controlnet_condition[plan.cfg_index:plan.cfg_index + 1] if plan.cfg_groups == 2 else controlnet_condition
+            ctrl_local = cc[:, f0:f0 + fl].to(device=dev, dtype=torch.float16).contiguous()
+            pipe.controlnet.prepare()
+            pipe.controlnet._cond_tokens(ctrl_local, b_local, fl, H, W)     # once per clip, outside the recorded forward
+
+        def forward():
+            down = mid = None
+            if ctrl_local is not None:
+                down, mid, _ = pipe.controlnet.forward_tokens(tok_local, b_local, fl, H, W, t_dev, enc, ids_local, ctrl_local,
+                                                              controlnet_cond_scale, shard=self.shard)
+            return unet.forward_tokens(tok_local, b_local, fl, H, W, t_dev, enc, ids_local, down, mid, shard=self.shard)[0]
         recorded = None
         events_all = ops.GEMM_EVENTS
         for i, t in enumerate(sch.timesteps_host):
@@ -135,12 +158,10 @@ class DistDenoiser:
                 noise_local = recorded.run(ops.GEMM_EVENTS)
             elif self.use_replay:
                 with replay.record() as recorded:           # the first step runs for real and is recorded
-                    recorded.result, _ = unet.forward_tokens(tok_local, b_local, fl, H, W, t_dev, enc, ids_local,
-                                                             shard=self.shard)
+                    recorded.result = forward()
                 noise_local = recorded.result
             else:
-                noise_local, _ = unet.forward_tokens(tok_local, b_local, fl, H, W, t_dev, enc, ids_local,
-                                                     shard=self.shard)
+                noise_local = forward()
             # ---- exchange the noise prediction over all ranks (padded equal counts), compact, replicate the update
             if plan.cfg_groups == 2:
                 send[:fl * HW].copy_(noise_local)

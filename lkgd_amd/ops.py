@@ -374,6 +374,18 @@ def time_conv_out(tokens: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, nba
     return out
 
 
+def vit_patchify(x: torch.Tensor, size: int, patch: int) -> torch.Tensor:
+    """bilinear resize to size x size (align_corners=False) + patch unfold (include/lkgd_hip.h section 13):
+    fp32 [N, C, H, W] -> fp16 [N*(size/patch)^2, C*patch*patch]"""
+    _req(x, torch.float32, "x")
+    x = x.contiguous()
+    N, C_, H, W = x.shape
+    g = size // patch
+    out = torch.empty(N * g * g, C_ * patch * patch, dtype=torch.float16, device=x.device)
+    check(_L().lkgd_vit_patchify(x.data_ptr(), N, C_, H, W, out.data_ptr(), size, patch, _stream()), "lkgd_vit_patchify")
+    return out
+
+
 def scale(x: torch.Tensor, s: float) -> torch.Tensor:
     _req(x, torch.float16, "x")
     x = x.contiguous()

@@ -31,7 +31,8 @@ import torch
 import torch.nn as nn
 
 from ._lib import LkgdHipError
-from .patch import _model, _training_only, isinstance_str
+from .patch import _model, isinstance_str
+from .patch import set_patch_lora_mask          # noqa: F401  patch_FSM.py:790-814 is the same function
 
 
 def _fsm_blocks(model):
@@ -163,7 +164,15 @@ def track_tables(block, ctx):
     return cache[key]
 
 
-set_patch_lora_mask = _training_only("set_patch_lora_mask")
-hack_lora_forward = _training_only("hack_lora_forward")
-initialize_joint_lora = _training_only("initialize_joint_lora")
-set_joint_layer_requires_grad = _training_only("set_joint_layer_requires_grad")
+def set_joint_layer_requires_grad(model, requires_grad):
+    """patch_FSM.py:72-90,:816-827 (training knob, literal): the fuse convolution's parameters"""
+    for _, m in _fsm_blocks(model):
+        if hasattr(m, "conv_fuse"):
+            m.conv_fuse.requires_grad_(requires_grad)
+    return model
+
+
+def initialize_joint_lora(model, adapter_name, joint_adapter_name):
+    """patch_FSM.py:843-854 calls ``ToMeBlock.initialize_joint_lora``, which patch_FSM.py only has as a comment (:107-120):
+    the reference raises AttributeError here; so does this"""
+    raise AttributeError("'ToMeBlock' object has no attribute 'initialize_joint_lora' (commented out in patch_FSM.py:107-120)")

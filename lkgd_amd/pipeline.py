@@ -297,6 +297,10 @@ class StableVideoDiffusionPipeline:
         sch._step_index = num_inference_steps
         return latents
 
+    def _latents_for_decode(self, latents: torch.Tensor) -> torch.Tensor:
+        """hook between the loop and the VAE decode (identity here; the flow pipeline un-normalises)"""
+        return latents
+
     def _graphed_forward(self, Bc: int, F: int, H: int, W: int, enc: torch.Tensor, ids: torch.Tensor):
         """HIP-graph replay of ``unet.forward_tokens`` for fixed shapes / conditioning.  Static buffers: input tokens,
         timestep scalar; the captured kernels are exactly the ones the eager path launches (same stream semantics:
@@ -407,10 +411,45 @@ class StableVideoDiffusionPipeline:
                            callback_on_step_end, callback_on_step_end_tensor_inputs, controlnet_condition,
                            controlnet_cond_scale)
         if output_type != "latent":
-            frames = self.decode_latents(lat, num_frames, decode_chunk_size)
+            frames = self.decode_latents(self._latents_for_decode(lat), num_frames, decode_chunk_size)
             frames = tensor2vid(frames, self.image_processor, output_type=output_type)               # reference :644
         else:
             frames = lat
         if not return_dict:
             return frames
         return StableVideoDiffusionPipelineOutput(frames=frames)
+
+
+class StableVideoDiffusionPipelineControlNet(StableVideoDiffusionPipeline):
+    """/root/reference/pipeline/pipeline_stable_video_diffusion_controlnet.py: ``controlnet_condition`` is the SECOND positional
+    argument (:352-376); the loop runs the ControlNet-SVD encoder before the UNet every step (:582-607)"""
+
+    def __call__(self, image, controlnet_condition=None, height: int = 576, width: int = 1024, num_frames=None,
+                 num_inference_steps: int = 25, min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0,
+                 fps: int = 7, motion_bucket_id: int = 127, noise_aug_strength: float = 0.02, decode_chunk_size=None,
+                 num_videos_per_prompt=1, generator=None, latents=None, output_type="pil", callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs=["latents"], return_dict: bool = True, controlnet_cond_scale=1.0,
+                 batch_size=1, **extensions):
+        return super().__call__(image, height, width, num_frames, num_inference_steps, min_guidance_scale,
+                                max_guidance_scale, fps, motion_bucket_id, noise_aug_strength, decode_chunk_size,
+                                num_videos_per_prompt, generator, latents, output_type, callback_on_step_end,
+                                callback_on_step_end_tensor_inputs, return_dict,
+                                controlnet_condition=self._condition(controlnet_condition),
+                                controlnet_cond_scale=controlnet_cond_scale, **extensions)
+
+    def _condition(self, controlnet_condition):
+        return controlnet_condition
+
+
+class StableVideoDiffusionPipelineControlNetFlow(StableVideoDiffusionPipelineControlNet):
+    """/root/reference/pipeline/pipeline_stable_video_diffusion_controlnet_flow.py (BASELINE.json configs[3]) AS THE
+    REFERENCE RUNS IT: same signature, but its ControlNet call and the condition's preprocessing are commented out
+    (:548-553,:590-607) - ``controlnet_condition`` is accepted and unused, the UNet runs without residuals - and the
+    denoised latents are flow latents, un-normalised before the VAE decode (:641, utils/optical_flow.py:62-77)."""
+
+    def _condition(self, controlnet_condition):
+        return None
+
+    def _latents_for_decode(self, latents: torch.Tensor) -> torch.Tensor:
+        from .optical_flow import optical_flow_latent_unnormalize
+        return optical_flow_latent_unnormalize(latents)

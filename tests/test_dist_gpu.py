@@ -79,6 +79,66 @@ def _worker(rank, world, port, frames, guidance_on, q):
         dist.destroy_process_group()
 
 
+def _worker_cn(rank, world, port, frames, q):
+    """BASELINE.json configs[3]-style combination under sharding: the LKGD UNet (domain / flow features) with the
+    ControlNet-SVD encoder in the loop (pipeline_stable_video_diffusion_controlnet.py:582-607)"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkgd_amd import controlnet as pc
+        from lkgd_amd import unet as pu
+        from lkgd_amd.dist_run import DistDenoiser
+        from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+        dev = torch.device("cuda", 0)
+        cfg = pu.UNetConfig(sample_size=8, block_out_channels=(64, 128, 128, 128), num_attention_heads=(1, 2, 2, 2),
+                            addition_time_embed_dim=64, projection_class_embeddings_input_dim=192, num_frames=4)
+        unet = pu.UNetSpatioTemporalConditionModel(cfg).half().to(dev)
+        pu.init_synthetic_weights_(unet, seed=5)
+        cn = pc.ControlNetSDVModel(cfg).half().to(dev)
+        pu.init_synthetic_weights_(cn, seed=6)          # also fills the zero convolutions: the residuals matter
+        pipe = StableVideoDiffusionPipeline(unet=unet, controlnet=cn)
+        lat0, img, emb, ids = _inputs(frames, True)
+        g = torch.Generator().manual_seed(78)
+        ctrl = (2.0 * torch.rand(1, frames, 3, 64, 64, generator=g) - 1.0).repeat(2, 1, 1, 1, 1).half()
+        dom, flow = torch.randn(1, 1, 1000, generator=g).half(), torch.randn(1, 1, 1000, generator=g).half()
+        pipe.scheduler.set_timesteps(2)
+        s0 = float(pipe.scheduler.init_noise_sigma)
+        runner = DistDenoiser(pipe, world, rank, frames, cfg=True)
+        args = ((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2, 1.0, 3.0)
+        out = runner.denoise(*args, domain_features=dom.to(dev), flow_features=flow.to(dev),
+                             controlnet_condition=ctrl.to(dev), controlnet_cond_scale=0.8)
+        res = {"rank": rank, "out": out.float().cpu()}
+        if rank == 0:
+            args = ((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2, 1.0, 3.0)
+            res["ref"] = pipe.denoise(*args, domain_features=dom.to(dev), flow_features=flow.to(dev),
+                                      controlnet_condition=ctrl.to(dev), controlnet_cond_scale=0.8).float().cpu()
+            res["plain"] = pipe.denoise(*args, domain_features=dom.to(dev), flow_features=flow.to(dev)).float().cpu()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames", [(2, 4), (4, 5)])
+def test_sharded_controlnet_lk_loop_equals_single_process(world, frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cn, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0 = [r for r in results if "ref" in r][0]
+    ref = r0["ref"]
+    assert torch.isfinite(ref).all()
+    assert ((r0["plain"] - ref).norm() / ref.norm()).item() > 2e-2      # the ControlNet residuals really enter
+    for r in results:
+        rel = ((r["out"] - ref).norm() / ref.norm()).item()
+        assert rel <= 8e-3, f"rank {r['rank']}: sharded ControlNet + LK loop vs single process: relative L2 {rel:.3e}"
+
+
 @pytest.mark.parametrize("world,frames,guidance_on", [(2, 4, True), (4, 5, True), (2, 5, False), (4, 6, False)])
 def test_sharded_loop_equals_single_process(world, frames, guidance_on):
     ctx = mp.get_context("spawn")

@@ -126,8 +126,12 @@ def test_patch_api_bookkeeping():
     m._tome_info["args"]["flip"] = True
     m._joint_maps(ctx)
     assert ctx.spatial_partner.tolist() == [5, 4, 3, 2, 1, 0, 11, 10, 9, 8, 7, 6]
-    with pytest.raises(Exception):
-        patch.hack_lora_forward(m)
+    # the LoRA-mask entry points work on lkgd_amd.lora.Linear wrappers (tests/test_lora.py); without wrappers they are no-ops
+    assert patch.hack_lora_forward(m) is m and patch.set_patch_lora_mask(m, "xy_lora", [1, 0, 1, 0]) is m
+    assert m.lora_mask["xy_lora"].tolist() == [True, False, True, False]
+    from lkgd_amd import patch_FSM
+    with pytest.raises(AttributeError):
+        patch_FSM.initialize_joint_lora(m, "a", "b")       # commented out in the reference's ToMeBlock (patch_FSM.py:107-120)
 
 
 def test_forward_fails_loudly_without_gpu():

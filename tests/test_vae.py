@@ -200,3 +200,39 @@ def test_run_inference_svd_harness_end_to_end(tmp_path):
     assert len(gifs) == 1
     g = Image.open(os.path.join(out, "validation_images", gifs[0]))
     assert g.n_frames == 4 and g.size == (64, 64)
+
+
+def test_flow_latent_constants_and_round_trip():
+    """utils/optical_flow.py:62-77"""
+    from lkgd_amd import optical_flow as of
+    assert of.FLOW_LATENT_MEAN == 0.5020191669464111 and of.FLOW_LATENT_STD == 1.2818458080291748
+    x = torch.randn(2, 3, 4)
+    torch.testing.assert_close(of.optical_flow_latent_unnormalize(of.optical_flow_latent_normalize(x)), x)
+    torch.testing.assert_close(of.optical_flow_latent_normalize(x, scale=4.0),
+                               ((x * 4.0 - of.FLOW_LATENT_MEAN) / of.FLOW_LATENT_STD) / 4.0)
+    assert of.optical_flow_latent_unnormalize(torch.zeros(1, dtype=torch.float16)).dtype == torch.float16
+
+
+@pytest.mark.gpu
+def test_flow_pipeline_unnormalises_before_decode_and_ignores_the_condition(tmp_path):
+    """pipeline_stable_video_diffusion_controlnet_flow.py as the reference runs it (configs[3]): the vanilla loop, the
+    condition argument unused, flow latents un-normalised before the temporal VAE decode (:641)"""
+    from lkgd_amd import optical_flow as of
+    from lkgd_amd import run_inference_svd as rs
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline, StableVideoDiffusionPipelineControlNetFlow
+    d = rs.make_tiny_pipeline_dir(str(tmp_path / "svd"))
+    base = StableVideoDiffusionPipeline.from_pretrained(d)
+    flow = StableVideoDiffusionPipelineControlNetFlow.from_pretrained(d)
+    image = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    kw = dict(height=64, width=64, num_frames=4, num_inference_steps=2)
+    cond = torch.rand(4, 3, 64, 64)
+    lat = base(image, output_type="latent", generator=torch.Generator().manual_seed(4), **kw).frames
+    lat_f = flow(image, cond, output_type="latent", generator=torch.Generator().manual_seed(4), **kw).frames
+    assert torch.equal(lat, lat_f)                                   # same loop, condition unused
+    got = flow(image, cond, output_type="pt", generator=torch.Generator().manual_seed(4), **kw).frames
+    z = of.optical_flow_latent_unnormalize(lat).flatten(0, 1) / base.vae.config.scaling_factor
+    ref = base.vae.decode(z, num_frames=4).sample.float()
+    ref = ((ref / 2 + 0.5).clamp(0, 1)).reshape(1, 4, 3, 64, 64)
+    assert got.shape == ref.shape and (got.float().cpu() - ref.cpu()).abs().max() < 2e-3
+    plain = base(image, output_type="pt", generator=torch.Generator().manual_seed(4), **kw).frames
+    assert (plain.float() - got.float()).abs().max() > 1e-2           # the un-normalisation changes the decoded frames
