@@ -124,9 +124,11 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
   for (int j = 0; j < ntiles; ++j) {
     // tile j has landed (this thread's loads; the barrier publishes everyone's) and every wave is done with tile j-1,
     // whose stage takes tile j+1
+#ifndef ATT_X_NOSYNC      // timing knob (tools/micro/attn_knobs.sh): no DMA stream, no barrier - every tile reads stage 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (j + 1 < ntiles) ISSUE_TILE(j + 1, cur ^ 1);
+#endif
 #pragma unroll 1
     for (int sub = 0; sub < NSUB; ++sub) {
       if (NSUB > 1 && (j * KVB + sub * KVBLK) >= S) break;      // wave-uniform: the ragged tail has no second sub-tile
@@ -147,8 +149,16 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
+#ifdef ATT_X_NOKREAD     // timing knob: no K fragment reads
+          half8_t kf = qf[(ks + f) & 3];
+#else
           half8_t kf = *(const half8_t*)(kb + k_lds_off(32 * f + l31, ks * 2 + h));
+#endif
+#ifndef ATT_X_NOQK
           s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
+#else
+          s[f][ks] += (float)kf[0];
+#endif
         }
       }
       if (key_base + KVBLK > S) {   // ragged last sub-tile: mask keys >= S
@@ -161,6 +171,9 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
           }
       }
       // ---- does the reference have to move?  per-lane max as a tree of 3-input maxima, one wave vote
+#ifdef ATT_X_NOMAX
+      float mx = s[0][0];
+#else
       float mx0 = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
       float mx1 = fmaxf(fmaxf(s[1][0], s[1][1]), s[1][2]);
 #pragma unroll
@@ -169,8 +182,16 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
         mx1 = fmaxf(fmaxf(mx1, s[1][r]), s[1][r + 1]);
       }
       float mx = fmaxf(fmaxf(mx0, mx1), fmaxf(s[0][15], s[1][15]));
+#endif
       const bool first = (j == 0 && sub == 0);
+      // (Tried and dropped in round 2: not computing the tile maximum at all and voting on the row sum instead, redoing the
+      // tile from LDS in the rare case - the exponentials then all have to finish before the vote, the compiler can no longer
+      // interleave them with the P.V MFMAs, and the kernel needs 152 registers: 3 instead of 4 waves per SIMD.)
+#ifdef ATT_X_NOMAX       // timing knob: no per-tile maximum / vote
+      if (first) {
+#else
       if (first || __any(mx > ATT_THR)) {
+#endif
         // (the two lane halves hold disjoint keys of the same query: one reference per query)
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float tgt = mb + mx;                                  // the tile's true maximum
@@ -201,8 +222,14 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
           half8_t pv;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
+#ifdef ATT_X_NOEXP       // timing knob: no exponentials
+            float p = s[f][ss * 8 + e];
+#else
             float p = __builtin_amdgcn_exp2f(s[f][ss * 8 + e]);
+#endif
+#ifndef ATT_X_NOSUM
             psum += p;
+#endif
             pv[e] = (half_t)p;
           }
           pf[f][ss] = pv;
@@ -217,17 +244,27 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
 #pragma unroll
           for (int df = 0; df < 2; ++df) {     // d-fragment innermost: the two output accumulators alternate
             int row0 = 32 * f + 16 * ss + tr_row;
+#ifdef ATT_X_NOVREAD     // timing knob: no V^T fragment reads
+            half8_t vf = qf[(ss + df) & 3];
+#else
             fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
                 (__attribute__((address_space(3))) fp16x4_t*)(vb + v_lds_off(row0, df * 4 + tr_c) + tr_sub));
             fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
                 (__attribute__((address_space(3))) fp16x4_t*)(vb + v_lds_off(row0 + 8, df * 4 + tr_c) + tr_sub));
             half4_t lo4 = __builtin_bit_cast(half4_t, lo), hi4 = __builtin_bit_cast(half4_t, hi);
             half8_t vf = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+#ifndef ATT_X_NOPV
             oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[f][ss], oacc[df], 0, 0, 0);
+#else
+            oacc[df][(f * 2 + ss) & 15] += (float)vf[0] * (float)pf[f][ss][0];
+#endif
           }
       }
     }
+#ifndef ATT_X_NOSYNC
     cur ^= 1;
+#endif
   }
 
   // ---- normalise and store: lane owns query row qrow, d = 32*df + 8*(r>>2) + 4*h + (r&3)

@@ -223,7 +223,9 @@ def test_flow_pipeline_unnormalises_before_decode_and_ignores_the_condition(tmp_
     d = rs.make_tiny_pipeline_dir(str(tmp_path / "svd"))
     base = StableVideoDiffusionPipeline.from_pretrained(d)
     flow = StableVideoDiffusionPipelineControlNetFlow.from_pretrained(d)
-    image = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    import numpy as np
+    from PIL import Image
+    image = Image.fromarray(np.random.RandomState(3).randint(0, 256, (64, 64, 3), dtype=np.uint8))   # PIL: the CLIP branch resizes
     kw = dict(height=64, width=64, num_frames=4, num_inference_steps=2)
     cond = torch.rand(4, 3, 64, 64)
     lat = base(image, output_type="latent", generator=torch.Generator().manual_seed(4), **kw).frames
