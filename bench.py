@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--joint", action="store_true",
                     help="the `patch` joint-attention hooks (utils/util.py:561-606): TWO clips per call (the [start, end] pair of "
                          "the trans pipelines), masks [0,1,0,1], spatial + temporal joint branch (not the headline workload)")
+    ap.add_argument("--cogvideox", action="store_true",
+                    help="configs[4]: the CogVideoX-2B image-to-video DiT loop (49 frames x 720x480 -> 13 latent frames x 60x90, CFG, "
+                         "DDIM; NOT the headline workload, single GPU); a 'step' is one clip of --inference-steps DiT steps")
     ap.add_argument("--controlnet", action="store_true",
                     help="also run the ControlNet-SVD encoder every step (SURVEY.md 8f rank 1; not the headline workload)")
     return ap.parse_args()
@@ -197,8 +200,66 @@ def self_launch(args) -> int:
     return rc
 
 
+def bench_cogvideox(args):
+    """configs[4] on one GPU (lkgd_amd/cogvideox.py): random-init 1.69 B-parameter DiT + LK modules, synthetic latents / prompt
+    embeddings; prints its own JSON line (frames of the decoded video per second: 49 per clip)"""
+    from lkgd_amd import cogvideox as pc
+    from lkgd_amd import unet as pu
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = pc.DiTConfig(in_channels=32) if not args.tiny else pc.DiTConfig(
+        num_attention_heads=2, in_channels=32, time_embed_dim=64, num_layers=2, sample_width=12, sample_height=8, sample_frames=9,
+        max_text_seq_length=16)
+    with torch.device("meta"):
+        m = pc.CogVideoXTransformer3DModel(cfg)
+    m = m.to(torch.float16).to_empty(device=dev)
+    pu.init_synthetic_weights_(m, seed=0)
+    with torch.no_grad():
+        for n, p in m.named_parameters():      # adaLN modulation / gates small, as in a trained model's range
+            if ".linear." in n and ("norm1" in n or "norm2" in n or "norm_out" in n):
+                p.mul_(0.1)
+    g = torch.Generator().manual_seed(3)
+    f = (cfg.sample_frames - 1) // cfg.temporal_compression_ratio + 1
+    lat = torch.randn(1, f, 16, cfg.sample_height, cfg.sample_width, generator=g).half().to(dev)
+    img = (0.5 * torch.randn(1, f, 16, cfg.sample_height, cfg.sample_width, generator=g)).half().to(dev)
+    pe = torch.randn(2, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g).half().to(dev)
+    dom, flow = torch.randn(1, 1, 1000, generator=g).to(dev), torch.randn(1, 1, 1000, generator=g).to(dev)
+    steps = args.inference_steps if args.inference_steps != 25 else 50
+    sch = pc.CogVideoXDDIMScheduler()
+
+    def one_clip():
+        return pc.denoise(m, sch, lat, img, pe, dom, flow, steps, 6.0, True)
+    for _ in range(args.warmup):
+        one_clip()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_clip()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L = cfg.max_text_seq_length + f * (cfg.sample_height // 2) * (cfg.sample_width // 2)
+    D = cfg.num_attention_heads * 64
+    tflop = 2 * cfg.num_layers * (2.0 * L * D * D * 12 + 4.0 * L * L * D) / 1e12        # CFG batch 2: projections + FF, attention
+    line = {"metric": "decoded-video frames/sec of the CogVideoX-2B DiT loop (49f x 720x480, DDIM, CFG) - configs[4], NOT the headline",
+            "value": round(args.steps * cfg.sample_frames / dt, 4), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"CogVideoX-2B image-to-video DiT with the LK fuse, {cfg.sample_frames} frames x 720x480 "
+                                   f"({f} latent frames x {cfg.sample_height}x{cfg.sample_width}, {L} joint tokens), {steps} DDIM steps, "
+                                   "dynamic CFG 6.0" + (" [TINY - INVALID]" if args.tiny else ""),
+                       "parallelism": "single GPU"},
+            "finite_output": bool(torch.isfinite(out.float()).all().item()),
+            "dit_ms_per_forward": round(dt / args.steps / steps * 1e3, 2),
+            "dit_tflops": round(tflop / (dt / args.steps / steps), 1), "roofline": None, "cpu_baseline": None}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if args.cogvideox:
+        if args.gpus != 1:
+            raise SystemExit("--cogvideox is a single-GPU option")
+        return bench_cogvideox(args)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -124,7 +124,7 @@ int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 3. LayerNorm over the channel dimension of a token matrix, optional row-indexed bias added BEFORE normalising
- *    (frame positional embedding: x + emb[idx(row)]), idx as in (1).  gamma == beta == NULL: no affine (the UNet folds
+ *    (frame positional embedding: x + emb[idx(row)]), idx as in (1); C % 8 == 0, C <= 2048.  gamma == beta == NULL: no affine (the UNet folds
  *    gamma/beta of every LayerNorm into the Linear that consumes it: W' = W*diag(gamma), b' = b + W*beta).
  *    Replaces: F.layer_norm - BasicTransformerBlock.norm1/3, TemporalBasicTransformerBlock.norm_in/1/3
  *    (patch/patch.py:416,556,600,610,670) and `hidden_states_mix + emb` [EXT transformer_temporal.py].
@@ -274,6 +274,19 @@ int lkgd_time_conv_out(const void* tokens, int32_t ld, const float* w, const flo
  * ------------------------------------------------------------------------------------------------------------- */
 int lkgd_vit_patchify(const float* in, int64_t nimg, int32_t C, int32_t H, int32_t W, void* out, int32_t S, int32_t P,
                       lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 14. DiT glue (the CogVideoX blocks; CogVideo-main/finetune/models/cogvideox_i2v/
+ *     cogvideox_transformer_3d.py:126-158): everything else of a block is lkgd_gemm_f16 / lkgd_layernorm (rows up to 2048
+ *     channels) / lkgd_attn_spatial.
+ *     `lkgd_gelu_tanh`: F.gelu(approximate="tanh") of the feed-forward [EXT diffusers GELU], fp16, n % 8 == 0, in place allowed.
+ *     `lkgd_gated_add`: out = res + gate[g(row)] * x, gate fp32 [2 * batch, C]: the adaLN-zero gates of the text stream (rows
+ *       [0, split) of every batch entry's rows_per_batch rows) and of the video stream (the rest) - `hidden_states + gate_msa *
+ *       attn_hidden_states` / `encoder_hidden_states + enc_gate_msa * ...` (:139-140,:155-156) in one pass over the joint buffer.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_gelu_tanh(const void* x, void* y, int64_t n, lkgd_stream_t stream);
+int lkgd_gated_add(const void* x, int32_t ldx, const float* gate, const void* res, int32_t ldr, void* out, int32_t ldo,
+                   int64_t rows, int32_t C, int32_t rows_per_batch, int32_t split, lkgd_stream_t stream);
 
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);

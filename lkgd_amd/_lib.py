@@ -83,6 +83,8 @@ SYMBOLS = {
     "lkgd_softmax_rows": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "lkgd_time_conv_out": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "lkgd_vit_patchify": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "lkgd_gelu_tanh": (_i32, [_vp, _vp, _i64, _vp]),
+    "lkgd_gated_add": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "lkgd_version": (C.c_char_p, []),
 }
 

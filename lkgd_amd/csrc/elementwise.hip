@@ -267,3 +267,63 @@ extern "C" int lkgd_euler_step(const void* model_output, const void* sample, int
 }
 
 extern "C" const char* lkgd_version(void) { return "lkgd_hip 1 gfx950"; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// DiT glue (include/lkgd_hip.h section 14; CogVideoX blocks)
+//   lkgd_gelu_tanh : y = 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))   F.gelu(approximate="tanh"), fp16 in / out, in place ok
+//   lkgd_gated_add : out[r, :] = res[r, :] + gate[g(r), :] * x[r, :],  g(r) = (r / rows_per_batch) * 2 + ((r % rows_per_batch) >= split)
+//                    the adaLN-zero residual of the two token streams (text rows first, then video rows) of every batch entry
+__global__ void gelu_tanh_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const half8_t v = *(const half8_t*)(x + i * 8);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float f = (float)v[e];
+    const float u = 0.7978845608028654f * (f + 0.044715f * f * f * f);
+    // tanh(u) = 1 - 2 / (exp(2u) + 1); exp2-based, saturates cleanly for |u| large
+    const float t = 1.0f - 2.0f / (__builtin_amdgcn_exp2f(u * 2.885390081777927f) + 1.0f);
+    o[e] = (half_t)(0.5f * f * (1.0f + t));
+  }
+  *(half8_t*)(y + i * 8) = o;
+}
+
+extern "C" int lkgd_gelu_tanh(const void* x, void* y, int64_t n, lkgd_stream_t stream) {
+  if (!x || !y) return LKGD_E_NULL;
+  if (n <= 0 || n % 8) return LKGD_E_SHAPE;
+  if (!aligned16(x) || !aligned16(y)) return LKGD_E_ALIGN;
+  const long long n8 = n / 8, nblk = (n8 + 255) / 256;
+  if (nblk > 0x7fffffffLL) return LKGD_E_SHAPE;
+  hipLaunchKernelGGL(gelu_tanh_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, n8);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+__global__ void gated_add_kernel(const half_t* __restrict__ x, int ldx, const float* __restrict__ gate, const half_t* __restrict__ res,
+                                 int ldr, half_t* __restrict__ out, int ldo, long long rows, int C8, int rows_per_batch, int split) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C8) return;
+  const long long r = i / C8;
+  const int cv = (int)(i - r * C8);
+  const long long b = r / rows_per_batch;
+  const int g = (int)(b * 2 + ((r - b * rows_per_batch) >= split ? 1 : 0));
+  const half8_t xv = *(const half8_t*)(x + r * ldx + cv * 8), rv = *(const half8_t*)(res + r * ldr + cv * 8);
+  const float4_t g0 = *(const float4_t*)(gate + ((long long)g * C8 + cv) * 8), g1 = *(const float4_t*)(gate + ((long long)g * C8 + cv) * 8 + 4);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)rv[e] + (e < 4 ? g0[e & 3] : g1[e & 3]) * (float)xv[e]);
+  *(half8_t*)(out + r * ldo + cv * 8) = o;
+}
+
+extern "C" int lkgd_gated_add(const void* x, int32_t ldx, const float* gate, const void* res, int32_t ldr, void* out, int32_t ldo,
+                              int64_t rows, int32_t C, int32_t rows_per_batch, int32_t split, lkgd_stream_t stream) {
+  if (!x || !gate || !res || !out) return LKGD_E_NULL;
+  if (rows <= 0 || C <= 0 || C % 8 || rows_per_batch <= 0 || rows % rows_per_batch || split < 0 || split > rows_per_batch)
+    return LKGD_E_SHAPE;
+  if (ldx % 8 || ldr % 8 || ldo % 8 || !aligned16(x) || !aligned16(res) || !aligned16(out) || !aligned16(gate)) return LKGD_E_ALIGN;
+  const long long total = rows * (C / 8), nblk = (total + 255) / 256;
+  if (nblk > 0x7fffffffLL) return LKGD_E_SHAPE;
+  hipLaunchKernelGGL(gated_add_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, gate,
+                     (const half_t*)res, ldr, (half_t*)out, ldo, (long long)rows, C / 8, rows_per_batch, split);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}

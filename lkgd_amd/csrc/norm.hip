@@ -251,8 +251,9 @@ extern "C" int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, con
 // A row is handled by a group of L lanes (L = 4..64, power of two) with up to 3 x 16-byte vectors per lane, so that small
 // channel counts keep the lanes busy: C = 320 -> 16 lanes x 3 vectors, 4 rows per wave (83 % lane efficiency instead of
 // 62 % with one row per wave); reductions are log2(L) shuffle steps inside the group.  gamma/beta stay in registers.
-#define LN_MAXV 3
-template <int L, bool AFF>
+#define LN_MAXV 3          // 16-byte vectors per lane: rows up to 64 * 8 * 3 = 1536 channels
+#define LN_MAXV_WIDE 4     // the DiT's 1920-channel rows (L = 64 lanes x 4 vectors = 2048)
+template <int L, bool AFF, int NV = LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx, long long T, int C,
                                                         const float* gamma, const float* beta, float eps,
                                                         const half_t* rowbias, int ldrb, int d1, int m1, int d2,
@@ -262,10 +263,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx
   const int wave = threadIdx.x >> 6;
   const int sub = lane / L, li = lane % L;          // row slot inside the wave, lane inside the row group
   const int C8 = C >> 3;
-  float g[AFF ? LN_MAXV : 1][8], b[AFF ? LN_MAXV : 1][8];
+  float g[AFF ? NV : 1][8], b[AFF ? NV : 1][8];
   if (AFF) {
 #pragma unroll
-    for (int v = 0; v < LN_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
       int cv = li + L * v;
       if (cv >= C8) cv = C8 - 1;        // clamped lanes never store
       const float4_t g0 = *(const float4_t*)(gamma + cv * 8), g1 = *(const float4_t*)(gamma + cv * 8 + 4);
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx
        row0 += (long long)gridDim.x * rows_per_block) {
     const long long row = row0 + sub;
     const bool live = row < T;
-    float xv[LN_MAXV][8];
+    float xv[NV][8];
     float s = 0.f;
     long long idx = 0;
     if (rowbias && live) {
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx
       }
     }
 #pragma unroll
-    for (int v = 0; v < LN_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
       int cv = li + L * v;
       if (live && cv < C8) {
         half8_t h = *(const half8_t*)(x + row * ldx + cv * 8);
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx
     const float mean = s * invC;
     float q = 0.f;
 #pragma unroll
-    for (int v = 0; v < LN_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
       int cv = li + L * v;
       if (cv < C8) {
 #pragma unroll
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx
     for (int o = L / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
     const float rstd = rsqrtf(q * invC + eps);
 #pragma unroll
-    for (int v = 0; v < LN_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
       int cv = li + L * v;
       if (live && cv < C8) {
         half8_t o;
@@ -348,7 +349,7 @@ extern "C" int lkgd_layernorm(const void* x, int32_t ldx, int64_t T, int32_t C, 
                               lkgd_stream_t stream) {
   if (!x || !out) return LKGD_E_NULL;
   if ((gamma == nullptr) != (beta == nullptr)) return LKGD_E_NULL;     // both or neither (neither = no affine)
-  if (T <= 0 || C <= 0 || C % 8 || C > 64 * 8 * LN_MAXV) return LKGD_E_SHAPE;
+  if (T <= 0 || C <= 0 || C % 8 || C > 64 * 8 * LN_MAXV_WIDE) return LKGD_E_SHAPE;
   if (ldx % 8 || ldo % 8 || !aligned16(x) || !aligned16(out)) return LKGD_E_ALIGN;
   if (rowbias && (ldrb % 8 || !aligned16(rowbias) || rb_d1 <= 0 || rb_d2 <= 0 || rb_md <= 0)) return LKGD_E_SHAPE;
   const int C8 = C / 8;
@@ -366,6 +367,17 @@ extern "C" int lkgd_layernorm(const void* x, int32_t ldx, int64_t T, int32_t C, 
     hipLaunchKernelGGL((layernorm_kernel<LL, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
                        (const half_t*)x, ldx, (long long)T, C, gamma, beta, eps, (const half_t*)rowbias, ldrb,   \
                        rb_d1, rb_m1, rb_d2, rb_md, 0, (half_t*)out, ldo)
+  if (C8 > 64 * LN_MAXV) {          // 1536 < C <= 2048: one row per wave, four vectors per lane
+    if (gamma)
+      hipLaunchKernelGGL((layernorm_kernel<64, true, LN_MAXV_WIDE>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                         (const half_t*)x, ldx, (long long)T, C, gamma, beta, eps, (const half_t*)rowbias, ldrb, rb_d1, rb_m1,
+                         rb_d2, rb_md, 0, (half_t*)out, ldo);
+    else
+      hipLaunchKernelGGL((layernorm_kernel<64, false, LN_MAXV_WIDE>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                         (const half_t*)x, ldx, (long long)T, C, gamma, beta, eps, (const half_t*)rowbias, ldrb, rb_d1, rb_m1,
+                         rb_d2, rb_md, 0, (half_t*)out, ldo);
+    return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+  }
   switch (L) {
     case 4: LN_LAUNCH(4); break;
     case 8: LN_LAUNCH(8); break;

@@ -386,6 +386,26 @@ def vit_patchify(x: torch.Tensor, size: int, patch: int) -> torch.Tensor:
     return out
 
 
+def gelu_tanh_(x: torch.Tensor) -> torch.Tensor:
+    """F.gelu(x, approximate="tanh") in place (include/lkgd_hip.h section 14)"""
+    _req(x, torch.float16, "x")
+    if not x.is_contiguous():
+        raise _lib.LkgdHipError("gelu_tanh_ needs a contiguous tensor")
+    check(_L().lkgd_gelu_tanh(x.data_ptr(), x.data_ptr(), x.numel(), _stream()), "lkgd_gelu_tanh")
+    return x
+
+
+def gated_add(x: torch.Tensor, gate: torch.Tensor, res: torch.Tensor, rows_per_batch: int, split: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = res + gate[(row // rows_per_batch) * 2 + (row % rows_per_batch >= split)] * x  (section 14); gate fp32 [2*B, C]"""
+    _req(x, torch.float16, "x"); _req(res, torch.float16, "res"); _req(gate, torch.float32, "gate")
+    if out is None:
+        out = torch.empty_like(res)
+    check(_L().lkgd_gated_add(x.data_ptr(), _ld(x), gate.data_ptr(), res.data_ptr(), _ld(res), out.data_ptr(), _ld(out),
+                              x.shape[0], x.shape[1], rows_per_batch, split, _stream()), "lkgd_gated_add")
+    return out
+
+
 def scale(x: torch.Tensor, s: float) -> torch.Tensor:
     _req(x, torch.float16, "x")
     x = x.contiguous()

@@ -731,6 +731,71 @@ def gen_patch_lora(patch_mod, ref_stock):
         (out["single_all_ones"] - out["masked"]).abs().max()))
 
 
+DIT_SEED = 191
+
+
+def dit_inputs(cfg, seed=DIT_SEED + 1, batch=2):
+    g = torch.Generator().manual_seed(seed)
+    f = (cfg.sample_frames - 1) // cfg.temporal_compression_ratio + 1
+    return dict(hidden=torch.randn(batch, f, cfg.in_channels, cfg.sample_height, cfg.sample_width, generator=g).half().float(),
+                text=torch.randn(batch, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g).half().float(),
+                t=torch.tensor([721] * batch), domain=torch.randn(1, 1, 1000, generator=g),
+                flow=torch.randn(1, 1, 1000, generator=g))
+
+
+def gen_cogvideox():
+    """the reference's in-tree CogVideoX DiT (CogVideo-main/finetune/models/cogvideox_i2v/cogvideox_transformer_3d.py: block
+    :41-160, forward :473-638 incl. the latent-knowledge fuse on the text embeddings :519-582 and the un-patchify) executed over
+    the restated diffusers >= 0.32 pieces of oracle/cogvideox.py (bound by name: Attention, FeedForward, CogVideoXPatchEmbed,
+    CogVideoXLayerNormZero, AdaLayerNorm, the attention processor), tiny config"""
+    from oracle import cogvideox as oc
+    du = sys.modules["diffusers.utils"]
+    du.USE_PEFT_BACKEND = False
+    du.scale_lora_layers = lambda *a, **k: None
+    du.unscale_lora_layers = lambda *a, **k: None
+    sys.modules["diffusers.utils.torch_utils"].maybe_allow_in_graph = lambda c: c
+    at = _mod("diffusers.models.attention")
+    at.Attention, at.FeedForward = oc.Attention, oc.FeedForward
+    ap = sys.modules["diffusers.models.attention_processor"]
+    ap.CogVideoXAttnProcessor2_0, ap.FusedCogVideoXAttnProcessor2_0 = oc.CogVideoXAttnProcessor2_0, oc.CogVideoXAttnProcessor2_0
+    _mod("diffusers.models.cache_utils").CacheMixin = type("CacheMixin", (), {})
+    sys.modules["diffusers.models.embeddings"].CogVideoXPatchEmbed = oc.CogVideoXPatchEmbed
+
+    class _TE(ob.TimestepEmbedding):          # diffusers' signature (in_channels, time_embed_dim, act_fn, out_dim) / forward(x, cond)
+        def __init__(self, in_channels, time_embed_dim, act_fn="silu", out_dim=None):
+            assert act_fn == "silu"
+            super().__init__(in_channels, time_embed_dim, out_dim)
+
+        def forward(self, sample, condition=None):
+            assert condition is None
+            return super().forward(sample)
+    sys.modules["diffusers.models.embeddings"].TimestepEmbedding = _TE
+    _mod("diffusers.models.modeling_outputs").Transformer2DModelOutput = type("Transformer2DModelOutput", (), {})
+    nm = sys.modules["diffusers.models.normalization"]
+    nm.AdaLayerNorm, nm.CogVideoXLayerNormZero = oc.AdaLayerNorm, oc.CogVideoXLayerNormZero
+    ref = load_ref("CogVideo-main/finetune/models/cogvideox_i2v/cogvideox_transformer_3d.py", "ref_cogvideox_transformer_3d")
+    cfg = oc.TINY_DIT
+    kw = {k: v for k, v in cfg.__dict__.items()}
+    with torch.no_grad():
+        m = ref.CogVideoXTransformer3DModel(**kw)
+        m.init_quaternion_modules()
+        o = oc.CogVideoXTransformer3DModel(cfg)
+        assert sorted(k for k, _ in m.named_parameters()) == sorted(k for k, _ in o.named_parameters())
+        oc.init_weights_(m, DIT_SEED)
+        for p in m.parameters():
+            p.copy_(p.half().float())
+        inp = dit_inputs(cfg)
+        out = {"checksum": torch.tensor(checksum(m), dtype=torch.float64)}
+        out["out"] = m(inp["hidden"], inp["text"], inp["t"], inp["domain"], inp["flow"], return_dict=False)[0]
+        cap = {}
+        h = m.patch_embed.register_forward_pre_hook(lambda mod, a: (cap.setdefault("text", a[0].clone()), None)[1])
+        m(inp["hidden"], inp["text"], inp["t"], inp["domain"], inp["flow"], return_dict=False)
+        h.remove()
+        out["fused_text"] = cap["text"]
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "cogvideox.safetensors"))
+    print("cogvideox: out %s std %.4f, fused text std %.4f" % (tuple(out["out"].shape), out["out"].std(), out["fused_text"].std()))
+
+
 def _run_pipeline_loop(pipe_mod, unet, sched_mod, image, lat0, px, frames, steps_n, gen_seed):
     """the reference `__call__` (output_type="latent") with stand-in CLIP / VAE; returns what the loop tests need"""
     from oracle.scheduler import SchedulerConfig
@@ -844,6 +909,8 @@ def main():
     install_stubs()
     sys.path.insert(0, REF)
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "cogvideox":
+        return gen_cogvideox()
     if only == "patch_lora":
         for m in ("models", "utils"):
             _mod(m)
@@ -929,6 +996,7 @@ def main():
     gen_loop25_c1(pipe_mod, ref_stock, sched_mod)
     gen_unet_fullres(ref_stock)
     gen_unet_fullres_lk(ref_lk, fsm_mod)
+    gen_cogvideox()
 
 
 if __name__ == "__main__":
