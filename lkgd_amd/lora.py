@@ -228,7 +228,6 @@ def load_lora_into_unet(state_dict: Dict[str, torch.Tensor], network_alphas: Opt
         mod, which = _split_key(k, adapter_name)
         if mod is None:
             raise ValueError(f"unrecognised LoRA key '{k}'")
-        mod = mod.replace(".processor", "").replace("to_out_lora", "to_out.0") if "processor" in mod else mod
         per.setdefault(mod, {})[which] = v
     if not per:
         raise ValueError("empty LoRA state dict")

@@ -107,8 +107,12 @@ class StableVideoDiffusionPipeline:
             except ImportError as e:
                 raise LkgdHipError("image_encoder/ needs `transformers` (CLIPVisionModelWithProjection); pass "
                                    "`image_embeddings=` to __call__ instead") from e
-            image_encoder = CLIPVisionModelWithProjection.from_pretrained(os.path.join(root, "image_encoder"),
-                                                                          dtype=torch_dtype)
+            try:                      # transformers >= 4.56 spells the keyword `dtype`, older releases `torch_dtype`
+                image_encoder = CLIPVisionModelWithProjection.from_pretrained(os.path.join(root, "image_encoder"),
+                                                                              dtype=torch_dtype)
+            except TypeError:
+                image_encoder = CLIPVisionModelWithProjection.from_pretrained(os.path.join(root, "image_encoder"),
+                                                                              torch_dtype=torch_dtype)
         if feature_extractor is None and has("feature_extractor", "preprocessor_config.json"):
             from transformers import CLIPImageProcessor
             feature_extractor = CLIPImageProcessor.from_pretrained(os.path.join(root, "feature_extractor"))

@@ -2,7 +2,7 @@
 inputs, tracks and hook weights from here, so the fixtures hold expected outputs (and checksums) only."""
 import torch
 
-FULLRES_SEED = 131        # stock UNet weights of the full-resolution forward (oracle.init_weights_, rounded to fp16)
+FULLRES_SEED = 131        # seeds the INPUTS of the full-resolution fixtures (the stock UNet's weights are the c1 fixtures': seed 31)
 FULLRES_LK_SEED = 141     # LKGD UNet weights of the full-resolution LK + FSM-hook forward
 LOOP25_SEED = 151         # tiny-width 25-step loop
 #: latent geometry of BASELINE.json configs[1] with 2 of the 14 frames: CFG batch 2 x 2 frames x 72 x 128 (S = 9216)

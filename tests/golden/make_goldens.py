@@ -867,7 +867,7 @@ def gen_unet_fullres(ref_stock):
     inp = fullres_inputs()
     with torch.no_grad():
         m = ref_stock.UNetSpatioTemporalConditionControlNetModel(**SVD_CONFIG.__dict__)
-        ou.init_weights_(m, FULLRES_SEED)
+        ou.init_weights_(m, C1_SEED)          # the weights of the other real-width fixtures (one 1.5 B-parameter init per test session)
         for p in m.parameters():
             p.copy_(p.half().float())
         y = m(inp["sample"], inp["t"], inp["enc"], added_time_ids=inp["ids"], return_dict=False)[0]

@@ -16,7 +16,7 @@ import pytest
 import torch
 from safetensors.torch import load_file
 
-from golden.fullres_cases import (FULLRES_LK_SEED, FULLRES_SEED, fullres_inputs, fullres_tracks, seed_conv_fuse_)
+from golden.fullres_cases import FULLRES_LK_SEED, fullres_inputs, fullres_tracks, seed_conv_fuse_
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -50,9 +50,11 @@ def _gate(got, ref, what):
     assert rel <= 1e-2 and mx <= 5e-2, f"{what}: rel L2 {rel:.3e}, max abs {mx:.3e}"
 
 
-def test_stock_unet_full_resolution_vs_reference_golden(golden_dir):
+def test_stock_unet_full_resolution_vs_reference_golden(golden_dir, c1_oracle_model, c1_hip_model):
     g = load_file(os.path.join(golden_dir, "unet_fullres.safetensors"))
-    m = _hip_model(False, FULLRES_SEED, g["checksum"].item())
+    ck = float(sum(p.detach().double().abs().sum() for p in c1_oracle_model.parameters()))
+    assert abs(ck - g["checksum"].item()) <= 1e-9 * ck, "regenerated weights differ from the ones the reference ran with"
+    m = c1_hip_model                      # the real-width weights shared by the c1 / 25-step / full-resolution fixtures
     i = fullres_inputs()
     out = m(i["sample"].to(DEV), i["t"].to(DEV), i["enc"].to(DEV), added_time_ids=i["ids"].to(DEV), return_dict=False)[0]
     _gate(out, g["out"], "stock UNet @ 72x128")
