@@ -205,8 +205,12 @@ def bench_cogvideox(args):
     embeddings; prints its own JSON line (frames of the decoded video per second: 49 per clip)"""
     from lkgd_amd import cogvideox as pc
     from lkgd_amd import unet as pu
-    dev = torch.device("cuda", 0)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(os.environ.get("LKGD_DIST_BACKEND", "nccl"))
     cfg = pc.DiTConfig(in_channels=32) if not args.tiny else pc.DiTConfig(
         num_attention_heads=2, in_channels=32, time_embed_dim=64, num_layers=2, sample_width=12, sample_height=8, sample_frames=9,
         max_text_seq_length=16)
@@ -227,41 +231,61 @@ def bench_cogvideox(args):
     steps = args.inference_steps if args.inference_steps != 25 else 50
     sch = pc.CogVideoXDDIMScheduler()
 
-    def one_clip():
-        return pc.denoise(m, sch, lat, img, pe, dom, flow, steps, 6.0, True)
+    if world > 1:
+        from lkgd_amd.dist_run import DistDiTDenoiser
+        runner = DistDiTDenoiser(m, sch, world, rank, f)
+
+        def one_clip():
+            return runner.denoise(lat, img, pe, dom, flow, steps, 6.0, True)
+    else:
+        def one_clip():
+            return pc.denoise(m, sch, lat, img, pe, dom, flow, steps, 6.0, True)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(device_ids=[dev.index]) if dist.get_backend() == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         one_clip()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_clip()
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     L = cfg.max_text_seq_length + f * (cfg.sample_height // 2) * (cfg.sample_width // 2)
     D = cfg.num_attention_heads * 64
     tflop = 2 * cfg.num_layers * (2.0 * L * D * D * 12 + 4.0 * L * L * D) / 1e12        # CFG batch 2: projections + FF, attention
     line = {"metric": "decoded-video frames/sec of the CogVideoX-2B DiT loop (49f x 720x480, DDIM, CFG) - configs[4], NOT the headline",
-            "value": round(args.steps * cfg.sample_frames / dt, 4), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
+            "value": round(args.steps * cfg.sample_frames / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"CogVideoX-2B image-to-video DiT with the LK fuse, {cfg.sample_frames} frames x 720x480 "
                                    f"({f} latent frames x {cfg.sample_height}x{cfg.sample_width}, {L} joint tokens), {steps} DDIM steps, "
                                    "dynamic CFG 6.0" + (" [TINY - INVALID]" if args.tiny else ""),
-                       "parallelism": "single GPU"},
+                       "parallelism": "single GPU" if world == 1 else f"cfg x latent-frame shards over {world} GPUs"},
             "finite_output": bool(torch.isfinite(out.float()).all().item()),
             "dit_ms_per_forward": round(dt / args.steps / steps * 1e3, 2),
             "dit_tflops": round(tflop / (dt / args.steps / steps), 1), "roofline": None, "cpu_baseline": None}
-    print(json.dumps(line), flush=True)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
-    if args.cogvideox:
-        if args.gpus != 1:
-            raise SystemExit("--cogvideox is a single-GPU option")
-        return bench_cogvideox(args)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    if args.cogvideox:
+        return bench_cogvideox(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -145,6 +145,11 @@ int lkgd_layernorm(const void* x, int32_t ldx, int64_t T, int32_t C, const float
 int lkgd_attn_spatial(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
                       void* out, int32_t ldo, int32_t nbatch, int32_t S, int32_t heads, const int32_t* kv_batch_map,
                       float scale, lkgd_stream_t stream);
+/* the same with Sq query rows and S key rows per batch entry (q / out hold nbatch * Sq rows, k / v nbatch * S): a frame-sharded
+ * DiT rank's local queries against the keys / values gathered from all ranks (lkgd_amd/cogvideox.py) */
+int lkgd_attn_spatial_qk(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
+                         int32_t ldo, int32_t nbatch, int32_t Sq, int32_t S, int32_t heads, const int32_t* kv_batch_map,
+                         float scale, lkgd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 5. Temporal self-attention: for every (batch b, pixel s, head h) attend over the F frames (F <= 32, head_dim 64).

@@ -65,6 +65,7 @@ SYMBOLS = {
     "lkgd_layernorm": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
                               _vp]),
     "lkgd_attn_spatial": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),
+    "lkgd_attn_spatial_qk": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),
     "lkgd_attn_temporal": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _f32,
                                   _vp]),
     "lkgd_prepare_unet_input": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),

@@ -308,12 +308,17 @@ class CogVideoXTransformer3DModel(nn.Module):
 
     # ---- the per-step forward ------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward_tokens(self, hidden_states: torch.Tensor, fused_text: torch.Tensor, timestep) -> torch.Tensor:
+    def forward_tokens(self, hidden_states: torch.Tensor, fused_text: torch.Tensor, timestep, shard=None) -> torch.Tensor:
         """hidden_states [B, F, C, h, w]; fused_text [B, L, 4096] fp16 (``fused_text`` of the prompt embeddings) ->
-        [B, F, out_channels, h, w] fp16"""
+        [B, F, out_channels, h, w] fp16.  ``shard`` (lkgd_amd.dist_run.ShardInfo): this rank holds ONE batch entry (its CFG
+        half) and the latent frames [f0, f0 + F) of the clip; everything is row-local except the attention, whose local
+        queries (the replicated text rows + the rank's video rows) attend to the keys / values of ALL frames, all-gathered
+        over the frame group every layer."""
         self.prepare()
         pk, cfg, dev = self._pk, self.config, self.device
         B, Fr, C_, H, W = hidden_states.shape
+        if shard is not None and B != 1:
+            raise LkgdHipError("frame sharding of the DiT supports one batch entry per rank")
         p, D = cfg.patch_size, self.inner_dim
         h, w = H // p, W // p
         Tt, Tv = fused_text.shape[1], Fr * h * w
@@ -340,7 +345,12 @@ class CogVideoXTransformer3DModel(nn.Module):
         txt = fused_text.to(device=dev, dtype=torch.float16).reshape(B * Tt, -1).contiguous()
         xh = hidden_states.to(device=dev, dtype=torch.float16)
         patches = xh.reshape(B, Fr, C_, h, p, w, p).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, Tv, C_ * p * p).contiguous()
-        pos = self._pos_table(Fr, h, w)
+        if shard is None:
+            pos = self._pos_table(Fr, h, w)
+        else:
+            pos = self._pos_table(shard.F_total, h, w)[shard.f0 * h * w:(shard.f0 + Fr) * h * w]
+            Tv_all = shard.F_total * h * w
+            KV = [torch.empty(Tt + Tv_all, D, dtype=torch.float16, device=dev) for _ in range(2)]
         for b in range(B):
             ops.gemm(txt[b * Tt:(b + 1) * Tt], pk.w_tx, X[b * L:b * L + Tt], M=Tt, N=D, K=txt.shape[1], bias=pk.b_tx)
             ops.gemm(patches[b], pk.w_pe, X[b * L + Tt:(b + 1) * L], M=Tv, N=D, K=C_ * p * p, bias=pk.b_pe, rowbias=pos,
@@ -364,7 +374,13 @@ class CogVideoXTransformer3DModel(nn.Module):
             ops.layernorm(q.view(T * heads, 64), bp.nq[0], bp.nq[1], 1e-6, out=q.view(T * heads, 64))     # per-head qk norm
             ops.layernorm(k.view(T * heads, 64), bp.nk[0], bp.nk[1], 1e-6, out=k.view(T * heads, 64))
             a = torch.empty(T, D, dtype=torch.float16, device=dev)
-            ops.attn_spatial(q, k, v, a, B, L, heads)
+            if shard is None:
+                ops.attn_spatial(q, k, v, a, B, L, heads)
+            else:                   # keys / values of every frame of this CFG half: text rows (replicated) + gathered video rows
+                for full, loc in zip(KV, (k, v)):
+                    full[:Tt].copy_(loc[:Tt])
+                    full[Tt:].copy_(shard.gather(loc[Tt:]))
+                ops.attn_spatial(q, KV[0], KV[1], a, 1, Tt + Tv_all, heads, Sq=L)
             o = torch.empty(T, D, dtype=torch.float16, device=dev)
             ops.gemm(a, bp.o[0], o, M=T, N=D, K=D, bias=bp.o[1])
             X = ops.gated_add(o, gates[i, 0].reshape(2 * B, D), X, L, Tt)

@@ -42,9 +42,11 @@ template <int NW, int KVB>
 __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel(const half_t* __restrict__ q, int ldq,
                                                               const half_t* __restrict__ k, int ldk,
                                                               const half_t* __restrict__ v, int ldv,
-                                                              half_t* __restrict__ out, int ldo, int S, int heads,
+                                                              half_t* __restrict__ out, int ldo, int Sq, int S, int heads,
                                                               const int* __restrict__ kvmap, float scale_log2e,
                                                               int nqb, int nwg) {
+  // Sq query rows per batch entry (q / out), S key rows per batch entry (k / v): equal except for a frame-sharded DiT rank,
+  // whose local queries attend to the gathered keys of all ranks
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -67,8 +69,8 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
   // ---- Q fragments (B operand of S^T = K.Q^T), pre-scaled: lane holds Q[qrow][16*ks + 8*h + 0..7] * scale*log2e
   constexpr int QBLK = NW * 32;
   const int qrow = qb * QBLK + w * 32 + l31;
-  const int qrow_c = qrow < S ? qrow : S - 1;
-  const half_t* qp = q + ((long long)n * S + qrow_c) * ldq + head * 64 + h * 8;
+  const int qrow_c = qrow < Sq ? qrow : Sq - 1;
+  const half_t* qp = q + ((long long)n * Sq + qrow_c) * ldq + head * 64 + h * 8;
   half8_t qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -270,8 +272,8 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
   // ---- normalise and store: lane owns query row qrow, d = 32*df + 8*(r>>2) + 4*h + (r&3)
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (qrow < S) {
-    half_t* op = out + ((long long)n * S + qrow) * ldo + head * 64 + 4 * h;
+  if (qrow < Sq) {
+    half_t* op = out + ((long long)n * Sq + qrow) * ldo + head * 64 + 4 * h;
 #pragma unroll
     for (int df = 0; df < 2; ++df)
 #pragma unroll
@@ -291,7 +293,7 @@ extern "C" void lkgd_debug_set_attn_kvb(int kvb) { attn_kvb_override = kvb; }
 
 template <int NW, int KVB>
 static int attn_launch(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
-                       int32_t ldo, int32_t nbatch, int32_t S, int32_t heads, const int32_t* kv_batch_map, float scale,
+                       int32_t ldo, int32_t nbatch, int32_t Sq, int32_t S, int32_t heads, const int32_t* kv_batch_map, float scale,
                        hipStream_t stream) {
   constexpr int LDS = ATT_NST * 2 * KVB * 128;
   LKGD_DEVICE_ONCE_BEGIN
@@ -300,30 +302,36 @@ static int attn_launch(const void* q, int32_t ldq, const void* k, int32_t ldk, c
       return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
   const int QBLK = NW * 32;
-  const int nqb = (S + QBLK - 1) / QBLK;
+  const int nqb = (Sq + QBLK - 1) / QBLK;
   const long long nwg = (long long)nqb * nbatch * heads;
   if (nwg > 0x7fffffffLL) return LKGD_E_SHAPE;
   hipLaunchKernelGGL((attn_spatial_kernel<NW, KVB>), dim3((unsigned)nwg), dim3(NW * 64), LDS, stream, (const half_t*)q, ldq,
-                     (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, S, heads, kv_batch_map,
+                     (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, Sq, S, heads, kv_batch_map,
                      scale * 1.4426950408889634f, nqb, (int)nwg);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+extern "C" int lkgd_attn_spatial_qk(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
+                                    void* out, int32_t ldo, int32_t nbatch, int32_t Sq, int32_t S, int32_t heads,
+                                    const int32_t* kv_batch_map, float scale, lkgd_stream_t stream) {
+  if (!q || !k || !v || !out) return LKGD_E_NULL;
+  if (nbatch <= 0 || S <= 0 || Sq <= 0 || heads <= 0) return LKGD_E_SHAPE;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LKGD_E_ALIGN;
+  if (ldq < heads * 64 || ldk < heads * 64 || ldv < heads * 64 || ldo < heads * 64) return LKGD_E_SHAPE;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || ((uintptr_t)out & 7)) return LKGD_E_ALIGN;
+  // queries per workgroup: 512 at S >= 8192, 256 at S >= 2304, else 128 (tools/attn_bench.py with ATTN_WAVES)
+  const int nw = attn_nw_override ? attn_nw_override : (Sq >= 8192 ? 16 : Sq >= 2304 ? 8 : 4);
+  const int kvb = attn_kvb_override ? attn_kvb_override : (nw == 16 ? ATT_KVB16 : 64);
+  hipStream_t st = (hipStream_t)stream;
+#define ATT_ARGS q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, S, heads, kv_batch_map, scale, st
+  if (nw == 16) return kvb == 128 ? attn_launch<16, 128>(ATT_ARGS) : attn_launch<16, 64>(ATT_ARGS);
+  if (nw == 8) return kvb == 128 ? attn_launch<8, 128>(ATT_ARGS) : attn_launch<8, 64>(ATT_ARGS);
+  return attn_launch<4, 64>(ATT_ARGS);
+#undef ATT_ARGS
 }
 
 extern "C" int lkgd_attn_spatial(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
                                  void* out, int32_t ldo, int32_t nbatch, int32_t S, int32_t heads,
                                  const int32_t* kv_batch_map, float scale, lkgd_stream_t stream) {
-  if (!q || !k || !v || !out) return LKGD_E_NULL;
-  if (nbatch <= 0 || S <= 0 || heads <= 0) return LKGD_E_SHAPE;
-  if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LKGD_E_ALIGN;
-  if (ldq < heads * 64 || ldk < heads * 64 || ldv < heads * 64 || ldo < heads * 64) return LKGD_E_SHAPE;
-  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || ((uintptr_t)out & 7)) return LKGD_E_ALIGN;
-  // queries per workgroup: 512 at S >= 8192, 256 at S >= 2304, else 128 (tools/attn_bench.py with ATTN_WAVES)
-  const int nw = attn_nw_override ? attn_nw_override : (S >= 8192 ? 16 : S >= 2304 ? 8 : 4);
-  const int kvb = attn_kvb_override ? attn_kvb_override : (nw == 16 ? ATT_KVB16 : 64);
-  hipStream_t st = (hipStream_t)stream;
-#define ATT_ARGS q, ldq, k, ldk, v, ldv, out, ldo, nbatch, S, heads, kv_batch_map, scale, st
-  if (nw == 16) return kvb == 128 ? attn_launch<16, 128>(ATT_ARGS) : attn_launch<16, 64>(ATT_ARGS);
-  if (nw == 8) return kvb == 128 ? attn_launch<8, 128>(ATT_ARGS) : attn_launch<8, 64>(ATT_ARGS);
-  return attn_launch<4, 64>(ATT_ARGS);
-#undef ATT_ARGS
+  return lkgd_attn_spatial_qk(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, S, S, heads, kv_batch_map, scale, stream);
 }

@@ -185,3 +185,75 @@ class DistDenoiser:
         ops.GEMM_EVENTS = events_all
         sch._step_index = num_inference_steps
         return latents
+
+
+class DistDiTDenoiser:
+    """BASELINE.json configs[4] over N GPUs: the CogVideoX DiT loop (lkgd_amd/cogvideox.py) with the SAME decomposition as the
+    SVD loop - CFG-parallel x slices of the clip's latent frames (13 latent frames: 2 GPUs = CFG halves, 4 = CFG x (7, 6),
+    8 = CFG x (4, 3, 3, 3)).  A rank holds the text tokens (226 rows, replicated - their stream is computed redundantly and stays
+    bit-identical across the frame group) and the video tokens of its frames; every per-token op (adaLN LayerNorms, projections,
+    qk norm, feed-forward, gated residuals) is local.  The one exchange per layer is the all-gather of the video keys and values
+    ([frames, 1350, 1920] fp16 each, padded to equal counts): the rank's queries then run the flash kernel against all 17 776
+    keys (``lkgd_attn_spatial_qk``, Sq < S).  Per forward a rank of 8 receives 30 layers x 2 x 10/13 x 67 MB = 3.1 GB over its
+    three links (~ 6.8 ms at 153 GB/s per link) next to ~ 33 ms of compute; once per step the noise prediction (1.1 MB) is
+    gathered over all ranks and the CFG combine + DDIM update are replicated.  No launch replay here: the modulation vectors
+    are recomputed by tensor ops every step."""
+
+    def __init__(self, transformer, scheduler, world: int, rank: int, latent_frames: int, cfg: bool = True):
+        if not dist.is_initialized():
+            raise LkgdHipError("torch.distributed is not initialised")
+        self.transformer, self.scheduler = transformer, scheduler
+        self.plan = make_plan(world, rank, latent_frames, cfg)
+        self.frame_group = None
+        for c in range(self.plan.cfg_groups):
+            ranks = list(range(c * self.plan.frame_shards, (c + 1) * self.plan.frame_shards))
+            g = dist.new_group(ranks) if self.plan.frame_shards > 1 else None
+            if c == self.plan.cfg_index:
+                self.frame_group = g
+        self.shard = ShardInfo(self.plan, self.frame_group)
+
+    @torch.no_grad()
+    def denoise(self, latents, image_latents, prompt_embeds, domain_features, flow_features, num_inference_steps: int = 50,
+                guidance_scale: float = 6.0, use_dynamic_cfg: bool = True) -> torch.Tensor:
+        """``lkgd_amd.cogvideox.denoise`` over the ranks; latents / image_latents [1, F, C, h, w], prompt_embeds [2, L, 4096]"""
+        from .cogvideox import dynamic_guidance
+        tr, sch, plan = self.transformer, self.scheduler, self.plan
+        dev = tr.device
+        B, F, C_, H, W = latents.shape
+        if B != 1 or F != plan.num_frames:
+            raise LkgdHipError("sharded DiT denoising handles one clip whose latent frame count matches the plan")
+        cfg = 2 if guidance_scale > 1.0 else 1
+        if plan.cfg_groups == 2 and cfg != 2:
+            raise LkgdHipError("shard plan was built for classifier-free guidance; got guidance_scale <= 1")
+        if plan.cfg_groups == 1 and cfg == 2 and plan.frame_shards > 1:
+            raise LkgdHipError("frame sharding without CFG-parallel needs guidance off (one batch entry per rank)")
+        sch.set_timesteps(num_inference_steps)
+        text = tr.fused_text(prompt_embeds.to(dev), domain_features.to(dev), flow_features.to(dev))      # replicated, once per clip
+        latents = latents.to(device=dev, dtype=torch.float16)
+        img = image_latents.to(device=dev, dtype=torch.float16)
+        fl, f0, fmax = plan.f_local, plan.f0, plan.f_max
+        co = tr.config.out_channels
+        per = co * H * W
+        send = torch.zeros(fmax * per, dtype=torch.float16, device=dev)
+        buf = torch.empty(plan.world * fmax * per, dtype=torch.float16, device=dev)
+        noise_full = torch.empty(cfg, F, co, H, W, dtype=torch.float16, device=dev)
+        sharded = plan.frame_shards > 1
+        for t in sch.timesteps.tolist():
+            if plan.cfg_groups == 2:
+                x = torch.cat([latents[:, f0:f0 + fl], img[:, f0:f0 + fl]], dim=2)
+                out = tr.forward_tokens(x, text[plan.cfg_index:plan.cfg_index + 1], float(t), shard=self.shard if sharded else None)
+                send[:fl * per].copy_(out.reshape(-1))
+                all_gather_into(buf, send)
+                for r in range(plan.world):
+                    ci, si = divmod(r, plan.frame_shards)
+                    n, fs = plan.splits[si], sum(plan.splits[:si])
+                    noise_full[ci, fs:fs + n].copy_(buf[r * fmax * per:r * fmax * per + n * per].reshape(n, co, H, W))
+            else:                      # one rank: the whole CFG batch, no exchange
+                x = torch.cat([latents] * cfg)
+                x = torch.cat([x, torch.cat([img] * cfg)], dim=2)
+                noise_full.copy_(tr.forward_tokens(x, text, float(t)))
+            noise = noise_full.float()
+            g = dynamic_guidance(guidance_scale, num_inference_steps, t) if use_dynamic_cfg else guidance_scale
+            n = noise[0:1] + g * (noise[1:2] - noise[0:1]) if cfg == 2 else noise
+            latents = sch.step(n, t, latents.float())[0].to(torch.float16)
+        return latents

@@ -219,11 +219,17 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
 
 
 def attn_spatial(q, k, v, out, nbatch: int, S: int, heads: int, kv_batch_map: Optional[torch.Tensor] = None,
-                 scale: float = 0.125):
+                 scale: float = 0.125, Sq: Optional[int] = None):
+    """S = key / value rows per batch entry; Sq = query rows (defaults to S; smaller on a frame-sharded DiT rank)"""
     _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v")
-    check(_L().lkgd_attn_spatial(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
-                                       out.data_ptr(), _ld(out), nbatch, S, heads, _ptr(kv_batch_map), scale,
-                                       _stream()), "lkgd_attn_spatial")
+    if Sq is None or Sq == S:
+        check(_L().lkgd_attn_spatial(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
+                                     out.data_ptr(), _ld(out), nbatch, S, heads, _ptr(kv_batch_map), scale,
+                                     _stream()), "lkgd_attn_spatial")
+    else:
+        check(_L().lkgd_attn_spatial_qk(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v),
+                                        out.data_ptr(), _ld(out), nbatch, Sq, S, heads, _ptr(kv_batch_map), scale,
+                                        _stream()), "lkgd_attn_spatial_qk")
     return out
 
 

@@ -139,6 +139,54 @@ def test_sharded_controlnet_lk_loop_equals_single_process(world, frames):
         assert rel <= 8e-3, f"rank {r['rank']}: sharded ControlNet + LK loop vs single process: relative L2 {rel:.3e}"
 
 
+def _worker_dit(rank, world, port, q):
+    """configs[4] under sharding: the CogVideoX DiT loop, CFG-parallel x latent-frame slices (3 latent frames over (2, 1))"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkgd_amd import cogvideox as pc
+        from lkgd_amd import unet as pu
+        from lkgd_amd.dist_run import DistDiTDenoiser
+        dev = torch.device("cuda", 0)
+        cfg = pc.DiTConfig(num_attention_heads=2, in_channels=32, time_embed_dim=64, num_layers=2, sample_width=12, sample_height=8,
+                           sample_frames=9, max_text_seq_length=16)
+        m = pc.CogVideoXTransformer3DModel(cfg).half().to(dev)
+        pu.init_synthetic_weights_(m, seed=4)
+        g = torch.Generator().manual_seed(79)
+        lat = torch.randn(1, 3, 16, 8, 12, generator=g).half()
+        img = (0.5 * torch.randn(1, 3, 16, 8, 12, generator=g)).half()
+        pe = torch.randn(2, 16, 4096, generator=g).half()
+        dom, flow = torch.randn(1, 1, 1000, generator=g), torch.randn(1, 1, 1000, generator=g)
+        runner = DistDiTDenoiser(m, pc.CogVideoXDDIMScheduler(), world, rank, 3, cfg=True)
+        out = runner.denoise(lat.to(dev), img.to(dev), pe.to(dev), dom.to(dev), flow.to(dev), 3, 6.0, True)
+        res = {"rank": rank, "out": out.float().cpu()}
+        if rank == 0:
+            res["ref"] = pc.denoise(m, pc.CogVideoXDDIMScheduler(), lat.to(dev), img.to(dev), pe.to(dev), dom.to(dev), flow.to(dev),
+                                    3, 6.0, True).float().cpu()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_dit_loop_equals_single_process(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dit, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = [r["ref"] for r in results if "ref" in r][0]
+    assert torch.isfinite(ref).all()
+    for r in results:
+        rel = ((r["out"] - ref).norm() / ref.norm()).item()
+        assert rel <= 8e-3, f"rank {r['rank']}: sharded DiT loop vs single process: relative L2 {rel:.3e}"
+
+
 @pytest.mark.parametrize("world,frames,guidance_on", [(2, 4, True), (4, 5, True), (2, 5, False), (4, 6, False)])
 def test_sharded_loop_equals_single_process(world, frames, guidance_on):
     ctx = mp.get_context("spawn")

@@ -537,3 +537,18 @@ def test_gemm_split_k_on_256x320_tiles():
     L.lkgd_debug_set_gemm_splitk(1)
     _close(_untokens(outs[0], Nimg, H, W), refc, what="256x320 split-K conv3x3")
     assert (outs[0].float() - outs[1].float()).abs().max().item() <= 4e-3 * refc.abs().max().item()
+
+
+def test_attn_spatial_fewer_queries_than_keys(ops):
+    """lkgd_attn_spatial_qk: Sq query rows against S key rows per batch entry (a frame-sharded DiT rank)"""
+    g = torch.Generator().manual_seed(9)
+    nb, heads, S, Sq = 2, 3, 200, 72
+    C = heads * 64
+    q = torch.randn(nb * Sq, C, generator=g).half().to(DEV)
+    k = torch.randn(nb * S, C, generator=g).half().to(DEV)
+    v = torch.randn(nb * S, C, generator=g).half().to(DEV)
+    out = torch.empty(nb * Sq, C, dtype=torch.float16, device=DEV)
+    ops.attn_spatial(q, k, v, out, nb, S, heads, Sq=Sq)
+    qf, kf, vf = (t.float().reshape(nb, -1, heads, 64).transpose(1, 2) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(nb * Sq, C)
+    assert (out.float() - ref).abs().max() < 4e-3
