@@ -27,6 +27,10 @@
 __device__ __forceinline__ int k_lds_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_lds_off(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4); }
 
+// Also measured and dropped in round 2: TWO 32-query tiles per wave (eight waves, two per SIMD, 232-256 registers; every K / V^T
+// fragment read from LDS feeding two MFMAs, two independent softmax chains per wave): bit-identical results, 893 instead of
+// 965 TFLOP/s at S = 9216 and 758 instead of 910 at S = 2304 - halving the resident waves costs more than the halved LDS reads
+// and the in-wave overlap return.
 // NW  = waves per workgroup (32 query rows each): a K/V tile staged once serves 32*NW queries
 // KVB = keys staged per barrier (64 or 128): two 64-key sub-tiles per barrier halve the lockstep points of the 16 waves
 //
