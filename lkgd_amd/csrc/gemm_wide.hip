@@ -29,6 +29,13 @@
 #else
 #define WIDE_ST(ptr, v) (*(ptr) = (v))
 #endif
+#ifdef WIDE_X_LDSOUT
+#define WIDE_LDS_OUT 1
+#endif
+#ifndef WIDE_LDS_OUT
+#define WIDE_LDS_OUT 0          // 1: output rows through LDS as 16-byte pieces of whole row segments (measured slower, see the epilogue)
+#endif
+#define WIDE_OUT_PITCH 336      // bytes per staged output row (320 + 16: rows start on different banks)
 #define WBM 256
 #define WBN 320
 #define WNT 512
@@ -113,9 +120,18 @@ __device__ __forceinline__ float4_t wide_read_acc() {
   return (float4_t){a, b, c, d};
 }
 
+template <int V> struct WideIC { static constexpr int value = V; };
+template <class F, int... Is> __device__ __forceinline__ void wide_static_for(F&& f, WideIC<Is>...) { (f(WideIC<Is>{}), ...); }
+template <class F> __device__ __forceinline__ void wide_for10(F&& f) {
+  wide_static_for(f, WideIC<0>{}, WideIC<1>{}, WideIC<2>{}, WideIC<3>{}, WideIC<4>{}, WideIC<5>{}, WideIC<6>{}, WideIC<7>{}, WideIC<8>{}, WideIC<9>{});
+}
+template <class F> __device__ __forceinline__ void wide_for5(F&& f) {
+  wide_static_for(f, WideIC<0>{}, WideIC<1>{}, WideIC<2>{}, WideIC<3>{}, WideIC<4>{});
+}
+
 // SPLIT = false is the production instantiation: ksplit folds to 1 and the slice bookkeeping disappears (with it in, the
 // allocator spilled 19-34 instead of 2-20 registers around the K-loop and every launch of this kernel got ~2 % slower)
-template <int MODE, bool SPLIT>
+template <int MODE, bool SPLIT, bool LDSOUT>
 __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, int tiles_n, int ksplit_arg, float* ws) {
   const int ksplit = SPLIT ? ksplit_arg : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -251,10 +267,17 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
 
   int cur = 0, kt = 0, tile = tile_begin;
   bool skip_wait = false;
+#ifdef WIDE_X_LATEWAIT     /* timing knob (results wrong): the second body after an epilogue leaves its stores in flight */
+  int late = 0;
+#endif
 #pragma unroll 1
   for (int s = 0; s < total; ++s) {
     // K-tile s must have landed (it is the only LDS-DMA batch in flight at this point); the K-tile body starts with the
     // workgroup barrier, issues K-tile s+1's loads into the other stage and computes K-tile s
+#ifdef WIDE_X_LATEWAIT
+    if (late == 1) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); skip_wait = true; }
+    late = skip_wait && late == 0 ? 1 : 0;
+#endif
     if (!skip_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     skip_wait = false;
     const int m_a = (cur ^ 1) * WSTAGE_BYTES + w * 1024;
@@ -276,6 +299,9 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
       asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // + the last MFMAs have left the pipe
       skip_wait = true;
       kt = 0;
+      int lane_e = lane;             // opaque copy: everything per-lane below is recomputed here, once per tile, instead of
+      asm volatile("" : "+v"(lane_e));   // being hoisted out of the persistent loop into registers the K-tile body needs
+      const int l15 = lane_e & 15, lq = lane_e >> 4;      // (shadow the kernel-scope ones)
       int tm, tn;
       supertile<4>(tile / ksplit, tiles_m, tiles_n, tm, tn);
       const int slice = tile % ksplit;
@@ -292,40 +318,55 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
       const half_t* rbl = (const half_t*)(smem + WRB_OFF + ep_par * (2 * WRB_STRIP)) + wc * 160 + 4 * lq;
       // rows below rb_bound use the first strip, the others the second (the map changes at most once inside the tile)
       const unsigned rb_bound = rb_lds ? ((unsigned)(tm * WBM) / (unsigned)p.rb_d1 + 1u) * (unsigned)p.rb_d1 : 0u;
-      auto epi = [&](int j, const float4_t (&e)[10]) {
+      // Output rows leave through LDS (round 2).  In the accumulator layout a lane holds 4 channels of ONE token row, so a
+      // direct store instruction writes 16 rows x 32 bytes - sixteen partial cache lines per instruction, every 128-byte line
+      // of the output touched by four different instructions - and with the stores compiled out the K = 320 projections of
+      // the 72x128 level ran 34-36 % faster (tools/micro/wide_knobs.sh NOSTORE).  The K-tile stage consumed last is free until
+      // the next body's loads (one barrier makes sure every wave is done reading it): each wave parks a token fragment
+      // (16 rows x 160 channels fp16, 336-byte pitch) there and writes it out as 16-byte pieces of whole 320-byte row segments.
+      constexpr bool lds_out = LDSOUT && !SPLIT;        // the launcher checks N % 320 == 0, ldc % 8 == 0, 16-byte aligned out
+      char* scr = smem + (cur ^ 1) * WSTAGE_BYTES + w * (16 * WIDE_OUT_PITCH);
+      if (lds_out) __builtin_amdgcn_s_barrier();
+      // accumulator fragments are read where they are used (one or two live at a time, not all ten of a token fragment)
+      auto epi = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         const long long m = m0 + j * 16;
-        if (m >= p.M) return;
+        const bool live = m < p.M;
+        if (!lds_out && !live) return;
         if (SPLIT) {                 // fp32 partial tile of this K slice; bias / residuals / rounding happen in the reduce pass
           float* dst = ws + ((long long)slice * p.M + m) * p.N;
-#pragma unroll
-          for (int i = 0; i < 10; ++i)
-            if (n0 + i * 16 < p.N) *(float4_t*)(dst + n0 + i * 16) = e[i];
+          wide_for10([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const float4_t ev = wide_read_acc<(4 * i + j) * 4>();
+            if (n0 + i * 16 < p.N) *(float4_t*)(dst + n0 + i * 16) = ev;
+          });
           return;
         }
-        if (MODE != LKGD_A_PLAIN || !p.geglu) {
+        const bool gg = MODE == LKGD_A_PLAIN && p.geglu;
+        if (!gg) {
           unsigned idx = 0;          // 32-bit row-map arithmetic: M < 2^24 is a launch condition of this kernel
-          if (rbp && !rb_lds) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) +
-                                     (unsigned)p.rb_c0) % (unsigned)p.rb_md;
+          if (rbp && !rb_lds && live) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) +
+                                             (unsigned)p.rb_c0) % (unsigned)p.rb_md;
           const int rb_sel = (unsigned)m < rb_bound ? 0 : WRB_STRIP / 2;
-#pragma unroll
-          for (int i = 0; i < 10; ++i) {
+          wide_for10([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const int n = n0 + i * 16;
+            float4_t v = wide_read_acc<(4 * i + j) * 4>();
             if (n < p.N) {
-              float4_t v = e[i];
               if (p.bias) v += *(const float4_t*)(bl + i * 16);
-              if (rbp) {
+              if (rbp && live) {
                 const half4_t rb = rb_lds ? *(const half4_t*)(rbl + rb_sel + i * 16)
                                           : *(const half4_t*)(rbp + (long long)idx * p.ldrb + n);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) v[x] += (float)rb[x];
               }
               v *= p.s_acc;
-              if (r1p) {
+              if (r1p && live) {
                 half4_t r = *(const half4_t*)(r1p + m * p.ldr1 + n);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) v[x] += p.r1 * (float)r[x];
               }
-              if (r2p) {
+              if (r2p && live) {
                 half4_t r = *(const half4_t*)(r2p + m * p.ldr2 + n);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) v[x] += p.r2 * (float)r[x];
@@ -333,33 +374,53 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
               half4_t o;
 #pragma unroll
               for (int x = 0; x < 4; ++x) o[x] = (half_t)v[x];
-              WIDE_STORE_GUARD WIDE_ST((half4_t*)(outp + WIDE_OUT_ROW(m) * p.ldc + n), o);
+              if (lds_out) *(half4_t*)(scr + l15 * WIDE_OUT_PITCH + (i * 16 + 4 * lq) * 2) = o;
+              else { WIDE_STORE_GUARD WIDE_ST((half4_t*)(outp + WIDE_OUT_ROW(m) * p.ldc + n), o); }
             }
-          }
+          });
         } else {
           // wave channels [0,80) = hidden, [80,160) = gate of output columns tn*160 + wc*80 + [0,80)
           const int oc0 = tn * 160 + wc * 80 + 4 * lq;
-#pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            float4_t hv = e[i], gv = e[i + 5];
+          wide_for5([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            float4_t hv = wide_read_acc<(4 * i + j) * 4>(), gv = wide_read_acc<(4 * (i + 5) + j) * 4>();
             if (p.bias) {
               hv += *(const float4_t*)(bl + i * 16);
               gv += *(const float4_t*)(bl + 80 + i * 16);
             }
+#ifdef WIDE_X_NOGELU     /* timing knob: the gate without its GELU */
+            const float2_t lo = __builtin_shufflevector(hv, hv, 0, 1) * __builtin_shufflevector(gv, gv, 0, 1);
+            const float2_t hi = __builtin_shufflevector(hv, hv, 2, 3) * __builtin_shufflevector(gv, gv, 2, 3);
+#else
             const float2_t lo = __builtin_shufflevector(hv, hv, 0, 1) * gelu_erf2(__builtin_shufflevector(gv, gv, 0, 1));
             const float2_t hi = __builtin_shufflevector(hv, hv, 2, 3) * gelu_erf2(__builtin_shufflevector(gv, gv, 2, 3));
+#endif
             const half4_t o = {(half_t)lo.x, (half_t)lo.y, (half_t)hi.x, (half_t)hi.y};
-            WIDE_STORE_GUARD WIDE_ST((half4_t*)(outp + WIDE_OUT_ROW(m) * p.ldc + oc0 + i * 16), o);
+            if (lds_out) *(half4_t*)(scr + l15 * WIDE_OUT_PITCH + (i * 16 + 4 * lq) * 2) = o;
+            else { WIDE_STORE_GUARD WIDE_ST((half4_t*)(outp + WIDE_OUT_ROW(m) * p.ldc + oc0 + i * 16), o); }
+          });
+        }
+        if (lds_out) {
+          // the fragment's rows as 16-byte pieces: piece c of the wave's 16 x (20 | 10) grid -> row c / per, column piece c % per
+          const int per = gg ? 10 : 20;                               // 16-byte pieces per row (80 | 160 channels)
+          const long long mrow0 = (long long)tm * WBM + wr * 64 + j * 16;
+          const int ncol0 = gg ? tn * 160 + wc * 80 : tn * WBN + wc * 160;
+#pragma unroll
+          for (int kk = 0; kk < 5; ++kk) {
+            const int c = lane_e + 64 * kk;
+            if (c < 16 * per) {
+              const int row = gg ? (c * 205) >> 11 : (c * 205) >> 12;   // c / 10, c / 20 for c < 320
+              const int cc = c - row * per;
+              const half8_t v = *(const half8_t*)(scr + row * WIDE_OUT_PITCH + cc * 16);
+              const long long mr = mrow0 + row;
+              if (mr < p.M) { WIDE_STORE_GUARD WIDE_ST((half8_t*)(outp + WIDE_OUT_ROW(mr) * p.ldc + ncol0 + cc * 8), v); }
+            }
           }
         }
       };
 #define WIDE_EPI(J)                                                                                                \
   {                                                                                                                \
-    const float4_t e[10] = {wide_read_acc<(0 + J) * 4>(),  wide_read_acc<(4 + J) * 4>(),  wide_read_acc<(8 + J) * 4>(),  \
-                            wide_read_acc<(12 + J) * 4>(), wide_read_acc<(16 + J) * 4>(), wide_read_acc<(20 + J) * 4>(), \
-                            wide_read_acc<(24 + J) * 4>(), wide_read_acc<(28 + J) * 4>(), wide_read_acc<(32 + J) * 4>(), \
-                            wide_read_acc<(36 + J) * 4>()};                                                        \
-    epi(J, e);                                                                                                     \
+    epi(WideIC<J>{});                                                                                              \
     __builtin_amdgcn_sched_barrier(0);  /* keep one token fragment's loads/stores from piling onto the next */   \
   }
       WIDE_EPI(0) WIDE_EPI(1) WIDE_EPI(2) WIDE_EPI(3)
@@ -369,20 +430,25 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's trailing loads must land before the LDS is released
 }
 
-template <int MODE>
+template <int MODE, bool LDSOUT>
 __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n) {
-  wide_body<MODE, false>(p, tiles_m, tiles_n, 1, nullptr);
+  wide_body<MODE, false, LDSOUT>(p, tiles_m, tiles_n, 1, nullptr);
 }
 template <int MODE>
 __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_split_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit, float* ws) {
-  wide_body<MODE, true>(p, tiles_m, tiles_n, ksplit, ws);
+  wide_body<MODE, true, false>(p, tiles_m, tiles_n, ksplit, ws);
 }
 
 // ksplit > 1: K is cut into ksplit equal slices (ksplit divides K / 64); the caller runs lkgd_gemm_splitk_reduce afterwards
+static int wide_lds_out_override = -1;     // A/B knob: 0 = direct 8-byte stores, 1 = rows through LDS where the shape allows it
+extern "C" void lkgd_debug_set_wide_lds_out(int on) { wide_lds_out_override = on; }
+
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
   LKGD_DEVICE_ONCE_BEGIN
-    const void* fns[6] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3>,
-                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>,
+    const void* fns[9] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, false>,
+                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>,
+                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, true>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, true>,
+                          (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>,
                           (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) != hipSuccess) return LKGD_E_LAUNCH;
@@ -394,12 +460,17 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
   int grid = ntiles < cus ? (int)ntiles : cus;
   if (d->M >= (1 << 24)) return LKGD_E_SHAPE;            // float-reciprocal row decomposition (gemm_common.h)
   float* ws = (float*)d->workspace;
+  // whole 320-column tiles, 16-byte aligned output rows: the rows leave through LDS (see the epilogue)
+  const bool lds_ok = WIDE_LDS_OUT && d->N % WBN == 0 && d->ldc % 8 == 0 && aligned16(d->out);
+  const bool lds_out = wide_lds_out_override < 0 ? lds_ok : (lds_ok && wide_lds_out_override != 0);
 #define WIDE_LAUNCH(MODE_)                                                                                              \
   {                                                                                                                     \
     if (ksplit > 1)                                                                                                     \
       hipLaunchKernelGGL(lkgd_gemm_wide_split_kernel<MODE_>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws); \
+    else if (lds_out)                                                                                                   \
+      hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n); \
     else                                                                                                                \
-      hipLaunchKernelGGL(lkgd_gemm_wide_kernel<MODE_>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);     \
+      hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, false>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n); \
   }
   if (d->mode == LKGD_A_PLAIN) WIDE_LAUNCH(LKGD_A_PLAIN)
   else if (d->mode == LKGD_A_CONV3X3) WIDE_LAUNCH(LKGD_A_CONV3X3)

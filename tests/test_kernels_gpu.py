@@ -24,12 +24,12 @@ def _close(got, ref, rtol=4e-3, what=""):
     assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
 
 
-@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel"])
+@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel", "duo"])
 def ops(request):
     """every GEMM/conv test runs against ALL kernel variants (128x128 two-stage, 256x128 three-stage ring, persistent
     streaming kernel with register epilogue)"""
     from lkgd_amd import _lib, ops
-    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5}[request.param])
+    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5, "duo": 6}[request.param])
     yield ops
     _lib.lib().lkgd_debug_set_gemm_variant(0)
 
@@ -537,6 +537,73 @@ def test_gemm_split_k_on_256x320_tiles():
     L.lkgd_debug_set_gemm_splitk(1)
     _close(_untokens(outs[0], Nimg, H, W), refc, what="256x320 split-K conv3x3")
     assert (outs[0].float() - outs[1].float()).abs().max().item() <= 4e-3 * refc.abs().max().item()
+
+
+def test_gemm_wide_rows_through_lds_match_direct_stores():
+    """the 256x320 kernel's two output paths (8-byte stores straight from the accumulator layout; whole 320-byte row
+    segments staged through LDS): bit-identical, on ragged M, a column-slice output (ldc > N), residual + row bias, GEGLU,
+    3x3 and temporal convolutions; rows past M and columns outside the slice stay untouched"""
+    from lkgd_amd import _lib, ops
+    from lkgd_amd.packing import pack_conv3x3, pack_geglu
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(29)
+
+    def both(fn, shape, cols=None):
+        outs = []
+        for on in (0, 1):
+            L.lkgd_debug_set_wide_lds_out(on)
+            buf = torch.full(shape, -7.0, dtype=torch.float16, device=DEV)
+            fn(buf if cols is None else buf[:, cols[0]:cols[1]])
+            outs.append(buf.cpu())
+        L.lkgd_debug_set_wide_lds_out(-1)
+        assert torch.equal(outs[0], outs[1])
+        return outs[1]
+
+    L.lkgd_debug_set_gemm_variant(4)
+    try:
+        # plain, ragged M, residual + row bias, output = columns [64, 64+640) of a 768-wide buffer
+        M, N, K = 256 * 5 + 77, 640, 320
+        a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+        b = torch.randn(N, generator=g)
+        res = _h(torch.randn(M, N, generator=g))
+        table = _h(torch.randn(5, N, generator=g))
+        idx = (torch.arange(M) // 300) % 5
+        out = both(lambda o: ops.gemm(a.to(DEV), w.to(DEV), o, M=M, N=N, K=K, bias=b.to(DEV), res1=res.to(DEV), r1=0.5,
+                                      rowbias=table.to(DEV), rowmap=(300, 1, 1, 5, 0)), (M + 3, 768), cols=(64, 64 + N))
+        _close(out[:M, 64:64 + N], a.float() @ w.float().T + b + table.float()[idx] + 0.5 * res.float(), what="wide via LDS")
+        assert (out[M:] == -7).all() and (out[:, :64] == -7).all() and (out[:, 64 + N:] == -7).all()
+        # GEGLU at C = 320 (interleave 80): output 1280 columns
+        M, C = 256 * 3 + 130, 320
+        a = _h(torch.randn(M, C, generator=g))
+        w = torch.randn(8 * C, C, generator=g) / C ** 0.5
+        b = torch.randn(8 * C, generator=g) * 0.1
+        wp, bp, half = pack_geglu(w, b, half=80)
+        out = both(lambda o: ops.gemm(a.to(DEV), wp.to(DEV), o, M=M, N=8 * C, K=C, bias=bp.to(DEV), geglu=half), (M + 1, 4 * C))
+        hid, gate = (a.float() @ _h(w).float().T + b).chunk(2, dim=-1)
+        _close(out[:M], hid * F.gelu(gate), what="wide geglu via LDS")
+        assert (out[M:] == -7).all()
+        # 3x3 conv 64 -> 320 on 3 images of 40x24 (2880 rows: ragged last tile), temporal conv 320 -> 320
+        Nimg, Cin, Cout, H, W = 3, 64, 320, 40, 24
+        x = _h(torch.randn(Nimg, Cin, H, W, generator=g))
+        wc = _h(torch.randn(Cout, Cin, 3, 3, generator=g) / 24)
+        bc = torch.randn(Cout, generator=g)
+        out = both(lambda o: ops.gemm(_tokens(x).to(DEV), pack_conv3x3(wc).to(DEV), o, M=Nimg * H * W, N=Cout, K=9 * Cin,
+                                      bias=bc.to(DEV), mode=ops.A_CONV3X3, Cin=Cin, conv=(H, W, H, W, 1, 0)),
+                   (Nimg * H * W, Cout))
+        _close(_untokens(out, Nimg, H, W), F.conv2d(x.float(), wc.float(), bc, padding=1), what="wide conv via LDS")
+        from lkgd_amd.packing import pack_tconv3
+        Bc, Fr, C, Ht, Wt = 1, 5, 320, 23, 10
+        x5 = _h(torch.randn(Bc, C, Fr, Ht, Wt, generator=g))
+        wt = _h(torch.randn(C, C, 3, 1, 1, generator=g) / (3 * C) ** 0.5)
+        bt = torch.randn(C, generator=g)
+        tok = x5.permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous()
+        out = both(lambda o: ops.gemm(tok.to(DEV), pack_tconv3(wt).to(DEV), o, M=Bc * Fr * Ht * Wt, N=C, K=3 * C, bias=bt.to(DEV),
+                                      mode=ops.A_TCONV3, Cin=C, tconv=(Fr, Ht * Wt)), (Bc * Fr * Ht * Wt, C))
+        reft = F.conv3d(x5.float(), wt.float(), bt, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, C)
+        _close(out, reft, what="wide tconv via LDS")
+    finally:
+        L.lkgd_debug_set_gemm_variant(0)
+        L.lkgd_debug_set_wide_lds_out(-1)
 
 
 def test_attn_spatial_fewer_queries_than_keys(ops):

@@ -82,7 +82,48 @@ def body(first, part):
     return " \\\n  ".join(lines)
 
 
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lkgd_amd", "csrc", "gemm_wide_ktile.inc")
+def duo_body(first):
+    """K-tile body of gemm_duo.hip (128 x 320 tiles, two workgroups of 4 waves per CU, BK = 32: ONE K-step per body).
+    Operands: %0-%3 x[j] token fragments, %4,%5 wf[2] weight fragment double buffer, %6 xa / %7 wa LDS address of token /
+    weight fragment 0 (fragment n at + n*1024: a fragment is 16 rows x 64 bytes, contiguous), %8,%9 pA[2] global sources of
+    this lane's two A chunks of the NEXT K-tile, %10-%14 oB[5] byte offsets of its five weight chunks from %15 (SGPR pair),
+    %16 m_a LDS destination (other stage) + this wave's first fragment.  Wave w stages A fragments w, w+4 and weight
+    fragments w, w+4, .., w+16: the destinations are 4 KiB apart."""
+    lines = [q("s_waitcnt lgkmcnt(0)"), q("s_barrier")]
+    for j in range(4):
+        lines.append(q("ds_read_b128 %%%d, %%6 offset:%d" % (j, j * 1024)))
+    lines.append(q("ds_read_b128 %4, %7"))
+    stage = []
+    for i in range(2):
+        m0 = q("s_mov_b32 m0, %16") if i == 0 else q("s_add_u32 m0, m0, 4096")
+        stage.append(m0 + " " + q("s_nop 0") + " " + q("global_load_lds_dwordx4 %%%d, off" % (8 + i)))
+    for i in range(5):
+        m0 = q("s_add_u32 m0, %16, 8192") if i == 0 else q("s_add_u32 m0, m0, 4096")
+        stage.append(m0 + " " + q("s_nop 0") + " " + q("global_load_lds_dwordx4 %%%d, %%15" % (10 + i)))
+    for i in range(10):
+        cur, nxt = 4 + (i & 1), 4 + ((i + 1) & 1)
+        if i < 9:
+            lines.append(q("ds_read_b128 %%%d, %%7 offset:%d" % (nxt, (i + 1) * 1024)))
+            if i < len(stage):
+                lines.append(stage[i])
+            lines.append(q("s_waitcnt lgkmcnt(1)"))
+        else:
+            lines.append(q("s_waitcnt lgkmcnt(0)"))
+        for j in range(4):
+            c = "0" if first else acc(i, j)
+            lines.append(q("v_mfma_f32_16x16x32_f16 %s, %%%d, %%%d, %s" % (acc(i, j), cur, j, c)))
+    return " \\\n  ".join(lines)
+
+
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lkgd_amd", "csrc")
+with open(os.path.join(root, "gemm_duo_ktile.inc"), "w") as f:
+    f.write("// GENERATED by tools/gen_wide_asm.py - do not edit.  K-tile body of gemm_duo.hip (see that script for operands).\n")
+    f.write("#define DUO_KTILE_ASM_FIRST \\\n  " + duo_body(True) + "\n\n")
+    f.write("#define DUO_KTILE_ASM_NEXT \\\n  " + duo_body(False) + "\n\n")
+    f.write("#define DUO_AGPR_CLOBBERS " + ", ".join('"a%d"' % i for i in range(160)) + "\n")
+print("wrote gemm_duo_ktile.inc")
+
+out = os.path.join(root, "gemm_wide_ktile.inc")
 with open(out, "w") as f:
     f.write("// GENERATED by tools/gen_wide_asm.py - do not edit.  K-tile body of gemm_wide.hip (see that script for operands).\n")
     f.write("#define WIDE_KTILE_ASM_FIRST_A \\\n  " + body(True, 0) + "\n\n")

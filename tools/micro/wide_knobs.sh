@@ -6,11 +6,12 @@ set -e
 cd "$(dirname "$0")/../../lkgd_amd/csrc"
 make -s
 OBJS=""
-for s in gemm gemm_stream gemm_rowpanel norm attn_spatial attn_temporal elementwise fsm conv_small image_ops; do OBJS="$OBJS $s.o"; done
+for s in gemm gemm_stream gemm_rowpanel norm attn_spatial attn_temporal elementwise fsm conv_small image_ops vae_ops; do OBJS="$OBJS $s.o"; done
 KERNEL=gemm_wide
-for knob in BASE NONEXT NOBAR "$@"; do
-  tag=${knob/=/}
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm -DWIDE_X_$knob -c $KERNEL.hip -o /tmp/${KERNEL}_$tag.o
+for knob in BASE "$@"; do
+  tag=${knob//=/}; tag=${tag//+/_}
+  defs=""; for k in ${knob//+/ }; do defs="$defs -DWIDE_X_$k"; done       # A+B=2: several knobs in one build
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm $defs -c $KERNEL.hip -o /tmp/${KERNEL}_$tag.o
   hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/${KERNEL}_$tag.o -o ../../tools/micro/libwide_$tag.so
 done
 ls -la ../../tools/micro/libwide_*.so
