@@ -321,13 +321,12 @@ static int check_desc(const lkgd_gemm_desc* d) {
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit);   // gemm_wide.hip
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
-extern "C" int lkgd_gemm_duo_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);      // gemm_duo.hip
 
 // tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128 ring,
 // 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320),
 // 5 = force the register-resident row-panel kernel where it applies (plain A, K <= 320),
 static int gemm_variant_override = 0;
-extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 6) ? v : 0; }
+extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 5) ? v : 0; }
 extern "C" void lkgd_debug_set_gemm_splitk(int on);
 
 // Split-K for the 256x320 kernel on few-row problems (< half the CUs get a tile): the smallest number of EQUAL K slices
@@ -389,14 +388,11 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
                        d->M < (1 << 24);
   const bool stream_ok = rows16 && d->geglu != 80;
   const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
-  // 128x320 tiles at two workgroups per CU (plain single-source A; its GEGLU epilogue reads the 80-wide interleave too)
-  const bool duo_ok = plain && d->csplit >= d->K && d->K % 32 == 0 && d->M < (1 << 24) && d->N >= 2 &&
-                      (d->geglu == 0 || (d->geglu == 80 && d->N % 320 == 0));
-  int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide (256x320), 5 = rowpanel, 6 = duo (128x320 x 2 per CU)
+  int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide (256x320), 5 = rowpanel
   int wide_ks = 1;
   if (d->geglu == 80) {
     if (!wide_ok) return LKGD_E_SHAPE;
-    pick = (v == 6 && duo_ok) ? 6 : 4;                                // 80-wide GEGLU interleave: the 320-wide tile kernels only
+    pick = 4;                                                         // 80-wide GEGLU interleave exists only in the 256x320 kernel
   } else if (v != 0) {
     pick = v;
   } else if (rp_ok && d->M >= 4096 && d->K >= 192 && (d->N != 320 || d->res1)) {
@@ -419,11 +415,9 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   }
   // applicability (forced variants fall back the same way)
   if (pick == 5 && !rp_ok) pick = 1;
-  if (pick == 6 && !duo_ok) pick = 4;
   if (pick == 4 && !wide_ok) pick = 3;
   if (pick == 3 && (!stream_ok || d->M <= 256)) pick = (d->K >= 960 && d->M > 256) ? 2 : 1;
-  if (d->geglu == 80 && pick != 4 && pick != 6) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the 320-wide tile kernels
-  if (pick == 6) return lkgd_gemm_duo_launch(d, (hipStream_t)stream, cus);
+  if (d->geglu == 80 && pick != 4) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the 256x320 kernels
   if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
   if (pick == 4) {
     if (v == 4) wide_ks = wide_split(d, tiles_wide, cus);      // forced variant: same slicing rule

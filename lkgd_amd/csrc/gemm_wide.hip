@@ -29,12 +29,6 @@
 #else
 #define WIDE_ST(ptr, v) (*(ptr) = (v))
 #endif
-#ifdef WIDE_X_LDSOUT
-#define WIDE_LDS_OUT 1
-#endif
-#ifndef WIDE_LDS_OUT
-#define WIDE_LDS_OUT 0          // 1: output rows through LDS as 16-byte pieces of whole row segments (measured slower, see the epilogue)
-#endif
 #define WIDE_OUT_PITCH 336      // bytes per staged output row (320 + 16: rows start on different banks)
 #define WBM 256
 #define WBN 320
@@ -318,12 +312,15 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
       const half_t* rbl = (const half_t*)(smem + WRB_OFF + ep_par * (2 * WRB_STRIP)) + wc * 160 + 4 * lq;
       // rows below rb_bound use the first strip, the others the second (the map changes at most once inside the tile)
       const unsigned rb_bound = rb_lds ? ((unsigned)(tm * WBM) / (unsigned)p.rb_d1 + 1u) * (unsigned)p.rb_d1 : 0u;
-      // Output rows leave through LDS (round 2).  In the accumulator layout a lane holds 4 channels of ONE token row, so a
-      // direct store instruction writes 16 rows x 32 bytes - sixteen partial cache lines per instruction, every 128-byte line
-      // of the output touched by four different instructions - and with the stores compiled out the K = 320 projections of
-      // the 72x128 level ran 34-36 % faster (tools/micro/wide_knobs.sh NOSTORE).  The K-tile stage consumed last is free until
-      // the next body's loads (one barrier makes sure every wave is done reading it): each wave parks a token fragment
-      // (16 rows x 160 channels fp16, 336-byte pitch) there and writes it out as 16-byte pieces of whole 320-byte row segments.
+      // Output rows through LDS (LDSOUT: the plain linears without GEGLU).  In the accumulator layout a lane holds 4 channels
+      // of ONE token row, so a direct store instruction writes 16 rows x 32 bytes; a CU sustains ~16 GB/s of those against
+      // 24-60 GB/s for 16-byte pieces of contiguous rows (tools/micro/store_bw.hip), and the short-K linears are store-bound
+      // (stores compiled out: -34 % on the K = 320 projections of the 72x128 level).  The K-tile stage consumed last is free
+      // until the next body's loads (one barrier makes sure every wave is done reading it): each wave parks a token fragment
+      // (16 rows x 160 channels fp16, 336-byte pitch) there and writes it out as 16-byte pieces of 320-byte row segments.
+      // Measured (profiles/r02_gemm_ldsout_ab.txt): +1-6 % on the plain linears, -2 % on the deep-K convolutions (the extra
+      // barrier and LDS pass cost more than their rare epilogue returns), -4-10 % with GEGLU (160-byte segments): used for
+      // the first only.
       constexpr bool lds_out = LDSOUT && !SPLIT;        // the launcher checks N % 320 == 0, ldc % 8 == 0, 16-byte aligned out
       char* scr = smem + (cur ^ 1) * WSTAGE_BYTES + w * (16 * WIDE_OUT_PITCH);
       if (lds_out) __builtin_amdgcn_s_barrier();
@@ -342,7 +339,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
           });
           return;
         }
-        const bool gg = MODE == LKGD_A_PLAIN && p.geglu;
+        const bool gg = MODE == LKGD_A_PLAIN && !lds_out && p.geglu;      // (the launcher never pairs GEGLU with LDSOUT)
         if (!gg) {
           unsigned idx = 0;          // 32-bit row-map arithmetic: M < 2^24 is a launch condition of this kernel
           if (rbp && !rb_lds && live) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) +
@@ -440,14 +437,13 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
 }
 
 // ksplit > 1: K is cut into ksplit equal slices (ksplit divides K / 64); the caller runs lkgd_gemm_splitk_reduce afterwards
-static int wide_lds_out_override = -1;     // A/B knob: 0 = direct 8-byte stores, 1 = rows through LDS where the shape allows it
+static int wide_lds_out_override = -1;     // A/B knob: 0 = direct 8-byte stores everywhere, 1 / -1 = rows through LDS where used
 extern "C" void lkgd_debug_set_wide_lds_out(int on) { wide_lds_out_override = on; }
 
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
   LKGD_DEVICE_ONCE_BEGIN
-    const void* fns[9] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, false>,
+    const void* fns[7] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, false>,
                           (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>,
-                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, true>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, true>,
                           (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>,
                           (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>};
     for (const void* f : fns)
@@ -460,18 +456,19 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
   int grid = ntiles < cus ? (int)ntiles : cus;
   if (d->M >= (1 << 24)) return LKGD_E_SHAPE;            // float-reciprocal row decomposition (gemm_common.h)
   float* ws = (float*)d->workspace;
-  // whole 320-column tiles, 16-byte aligned output rows: the rows leave through LDS (see the epilogue)
-  const bool lds_ok = WIDE_LDS_OUT && d->N % WBN == 0 && d->ldc % 8 == 0 && aligned16(d->out);
-  const bool lds_out = wide_lds_out_override < 0 ? lds_ok : (lds_ok && wide_lds_out_override != 0);
+  // plain linears without GEGLU, whole 320-column tiles, 16-byte aligned output rows: the rows leave through LDS (see the epilogue)
+  const bool lds_out = wide_lds_out_override != 0 && ksplit == 1 && d->mode == LKGD_A_PLAIN && !d->geglu && d->N % WBN == 0 &&
+                       d->ldc % 8 == 0 && aligned16(d->out);
 #define WIDE_LAUNCH(MODE_)                                                                                              \
   {                                                                                                                     \
     if (ksplit > 1)                                                                                                     \
       hipLaunchKernelGGL(lkgd_gemm_wide_split_kernel<MODE_>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws); \
-    else if (lds_out)                                                                                                   \
-      hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n); \
     else                                                                                                                \
       hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, false>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n); \
   }
+  if (lds_out)
+    hipLaunchKernelGGL((lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+  else
   if (d->mode == LKGD_A_PLAIN) WIDE_LAUNCH(LKGD_A_PLAIN)
   else if (d->mode == LKGD_A_CONV3X3) WIDE_LAUNCH(LKGD_A_CONV3X3)
   else if (d->mode == LKGD_A_TCONV3) WIDE_LAUNCH(LKGD_A_TCONV3)

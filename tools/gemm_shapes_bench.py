@@ -97,7 +97,7 @@ def run(kind, d, iters=5, variants=None):
         for v in variants:
             _lib.lib().lkgd_debug_set_gemm_variant(v)
             if kind == "geglu":
-                gw[0] = 80 if v in (4, 6) else (geglu_half(N, K) if v == 0 else 32)
+                gw[0] = 80 if v == 4 else (geglu_half(N, K) if v == 0 else 32)
             try:
                 t = once()
             except Exception:          # variant not applicable to this shape
@@ -140,34 +140,10 @@ def main_ldsout():
     print(f"{'TOTAL ms (x count)':34s}       {tot[0]:7.2f}  {tot[1]:7.2f}   {tot_f / tot[0] / 1e9:6.0f} -> {tot_f / tot[1] / 1e9:6.0f} TF/s")
 
 
-def main_duo():
-    """the linears: automatic dispatch vs the 256x320 kernel vs the duo kernel (128x320 tiles, two workgroups per CU) at
-    several start offsets of a CU's second workgroup"""
-    from lkgd_amd import _lib
-    warm()
-    staggers = [int(x) for x in os.environ.get("STAGGERS", "0,8,24").split(",")]
-    print(f"{'shape':34s} {'cnt':>4s}     auto     wide " + " ".join(f"duo@{g:<4d}" for g in staggers) + "  (ms per launch)")
-    tot = {}
-    for name, cnt, kind, d in shapes():
-        if kind not in ("lin", "geglu"):
-            continue
-        row = {}
-        flop, best = run(kind, d, variants=[0, 4])
-        row["auto"], row["wide"] = best[0], best[4]
-        for g in staggers:
-            _lib.lib().lkgd_debug_set_duo_stagger(g)
-            flop, best = run(kind, d, variants=[6])
-            row[g] = best[6]
-        for k, v in row.items():
-            tot[k] = tot.get(k, 0.0) + v * cnt
-        print(f"{name:34s} {cnt:4d}  " + "  ".join(f"{v:7.3f}" for v in row.values()), flush=True)
-    print(f"{'TOTAL ms (x count)':34s}       " + "  ".join(f"{v:7.2f}" for v in tot.values()))
-
-
 def main_ab():
     warm()
-    variants = [0, 1, 3, 4, 5, 6]
-    names = {0: "auto", 1: "t128", 2: "t256", 3: "strm", 4: "wide", 5: "rowp", 6: "duo"}
+    variants = [0, 1, 3, 4, 5]
+    names = {0: "auto", 1: "t128", 2: "t256", 3: "strm", 4: "wide", 5: "rowp"}
     print(f"{'shape':34s} {'cnt':>4s} " + " ".join(f"{names[v]:>8s}" for v in variants) + "   (ms per launch; * = best)")
     tot = {v: 0.0 for v in variants}
     tot_best = tot_f = 0.0
@@ -187,8 +163,6 @@ def main_ab():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ab":
         return main_ab()
-    if len(sys.argv) > 1 and sys.argv[1] == "duo":
-        return main_duo()
     if len(sys.argv) > 1 and sys.argv[1] == "ldsout":
         return main_ldsout()
     warm()
