@@ -201,6 +201,12 @@ int lkgd_add(const void* a, const void* b, void* y, int64_t n, lkgd_stream_t str
 int lkgd_scale(const void* x, void* y, int64_t n, float s, lkgd_stream_t stream);
 int lkgd_euler_step(const void* model_output, const void* sample, int32_t sample_is_f32, void* prev, int64_t n,
                     float sigma, float sigma_next, int32_t prediction_type, lkgd_stream_t stream);
+/* the stochastic ("churn") form of the same step, s_churn > 0 (scheduling_euler_discrete_karras_fix.py:485-497):
+ * sample += fp16(fp16(noise * s_noise) * churn) with churn = sqrt(sigma_hat^2 - sigma^2), sigma_hat = sigma * (gamma + 1),
+ * then the Euler step from sigma_hat to sigma_next.  noise: fp16, n elements, drawn by the caller (randn_tensor). */
+int lkgd_euler_step_churn(const void* model_output, const void* sample, int32_t sample_is_f32, const void* noise, void* prev,
+                          int64_t n, float sigma, float sigma_hat, float s_noise, float churn, float sigma_next,
+                          int32_t prediction_type, lkgd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 9. FSM hook row kernel (patch/patch_FSM.py:380-441, the track-guided fuse between even "src" and odd "dst" batch
@@ -292,6 +298,18 @@ int lkgd_vit_patchify(const float* in, int64_t nimg, int32_t C, int32_t H, int32
 int lkgd_gelu_tanh(const void* x, void* y, int64_t n, lkgd_stream_t stream);
 int lkgd_gated_add(const void* x, int32_t ldx, const float* gate, const void* res, int32_t ldr, void* out, int32_t ldo,
                    int64_t rows, int32_t C, int32_t rows_per_batch, int32_t split, lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 15. Cross-attention against a multi-token context, head_dim 64: the literal attn2 of BasicTransformerBlock
+ *     (patch/patch.py:526-549) and TemporalBasicTransformerBlock (patch/patch.py:660-668) - F.scaled_dot_product_attention of
+ *     AttnProcessor2_0 [EXT] with Lk > 1 keys.  (For SVD's one-token context the UNet folds attn2 into a row bias and never
+ *     calls this.)  q / out: [T, heads*64] token rows; k / v: [ncontexts*Lk, heads*64], context c owns rows [c*Lk, (c+1)*Lk);
+ *     row m attends to context idx(m) = ((m / rb_d1) * rb_m1 + m % rb_d2 + rb_c0) % rb_md, the row map of (1).
+ *     ncontexts * Lk <= 256.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_attn_cross(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out, int32_t ldo,
+                    int64_t T, int32_t heads, int32_t ncontexts, int32_t Lk, int32_t rb_d1, int32_t rb_m1, int32_t rb_d2,
+                    int32_t rb_md, int32_t rb_c0, float scale, lkgd_stream_t stream);
 
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);

@@ -77,6 +77,9 @@ SYMBOLS = {
     "lkgd_add": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "lkgd_scale": (_i32, [_vp, _vp, _i64, _f32, _vp]),
     "lkgd_euler_step": (_i32, [_vp, _vp, _i32, _vp, _i64, _f32, _f32, _i32, _vp]),
+    "lkgd_attn_cross": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                _f32, _vp]),
+    "lkgd_euler_step_churn": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "lkgd_fsm_rows": (_i32, [C.POINTER(FsmDesc), _vp]),
     "lkgd_conv3x3_small": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
     "lkgd_conv1d_reflect": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp]),

@@ -136,17 +136,21 @@ __global__ __launch_bounds__(256) void scale_kernel(const half_t* __restrict__ x
 }
 template <typename ST>
 __global__ __launch_bounds__(256) void euler_kernel(const half_t* __restrict__ mo, const ST* __restrict__ sample,
-                                                    half_t* __restrict__ prev, long long n, float sigma,
-                                                    float sigma_next, int vpred) {
+                                                    const half_t* __restrict__ noise, half_t* __restrict__ prev, long long n,
+                                                    float sigma, float sigma_hat, float s_noise, float churn, float sigma_next,
+                                                    int vpred) {
+  // sigma_hat = sigma * (gamma + 1); gamma > 0 ("churn", scheduling_euler_discrete_karras_fix.py:485-497) first adds
+  // noise * s_noise * sqrt(sigma_hat^2 - sigma^2) to the sample, each product rounded to fp16 as the reference's tensors are
   const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f);
   const float c_skip = sigma * sigma + 1.0f;
-  const float dt = sigma_next - sigma;
+  const float dt = sigma_next - sigma_hat;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float x = (float)sample[i];
+    float x = (float)sample[i];
+    if (noise) x += (float)(half_t)((float)(half_t)((float)noise[i] * s_noise) * churn);
     float x0;
     if (vpred) x0 = (float)(half_t)((float)mo[i] * c_out) + x / c_skip;
-    else x0 = x - (float)(half_t)((float)mo[i] * sigma);
-    prev[i] = (half_t)(x + (x - x0) / sigma * dt);
+    else x0 = x - (float)(half_t)((float)mo[i] * sigma_hat);
+    prev[i] = (half_t)(x + (x - x0) / sigma_hat * dt);
   }
 }
 
@@ -249,21 +253,36 @@ extern "C" int lkgd_scale(const void* x, void* y, int64_t n, float s, lkgd_strea
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 
-extern "C" int lkgd_euler_step(const void* model_output, const void* sample, int32_t sample_is_f32, void* prev,
-                               int64_t n, float sigma, float sigma_next, int32_t prediction_type,
-                               lkgd_stream_t stream) {
+static int euler_launch(const void* model_output, const void* sample, int32_t sample_is_f32, const void* noise, void* prev,
+                        int64_t n, float sigma, float sigma_hat, float s_noise, float churn, float sigma_next,
+                        int32_t prediction_type, lkgd_stream_t stream) {
   if (!model_output || !sample || !prev) return LKGD_E_NULL;
-  if (n <= 0 || !(sigma > 0.f)) return LKGD_E_SHAPE;
+  if (n <= 0 || !(sigma > 0.f) || !(sigma_hat >= sigma)) return LKGD_E_SHAPE;
   if (prediction_type != 0 && prediction_type != 1) return LKGD_E_MODE;
   if (sample_is_f32)
     hipLaunchKernelGGL(euler_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)model_output, (const float*)sample, (half_t*)prev, (long long)n, sigma,
-                       sigma_next, prediction_type);
+                       (const half_t*)model_output, (const float*)sample, (const half_t*)noise, (half_t*)prev, (long long)n,
+                       sigma, sigma_hat, s_noise, churn, sigma_next, prediction_type);
   else
     hipLaunchKernelGGL(euler_kernel<half_t>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)model_output, (const half_t*)sample, (half_t*)prev, (long long)n, sigma,
-                       sigma_next, prediction_type);
+                       (const half_t*)model_output, (const half_t*)sample, (const half_t*)noise, (half_t*)prev, (long long)n,
+                       sigma, sigma_hat, s_noise, churn, sigma_next, prediction_type);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+extern "C" int lkgd_euler_step(const void* model_output, const void* sample, int32_t sample_is_f32, void* prev,
+                               int64_t n, float sigma, float sigma_next, int32_t prediction_type,
+                               lkgd_stream_t stream) {
+  return euler_launch(model_output, sample, sample_is_f32, nullptr, prev, n, sigma, sigma, 0.f, 0.f, sigma_next,
+                      prediction_type, stream);
+}
+
+extern "C" int lkgd_euler_step_churn(const void* model_output, const void* sample, int32_t sample_is_f32, const void* noise,
+                                     void* prev, int64_t n, float sigma, float sigma_hat, float s_noise, float churn,
+                                     float sigma_next, int32_t prediction_type, lkgd_stream_t stream) {
+  if (!noise) return LKGD_E_NULL;
+  return euler_launch(model_output, sample, sample_is_f32, noise, prev, n, sigma, sigma_hat, s_noise, churn, sigma_next,
+                      prediction_type, stream);
 }
 
 extern "C" const char* lkgd_version(void) { return "lkgd_hip 1 gfx950"; }

@@ -244,6 +244,16 @@ def attn_temporal(q, k, v, out, B: int, F: int, S: int, heads: int, kv_b_map: Op
     return out
 
 
+def attn_cross(q, k, v, out, heads: int, ncontexts: int, Lk: int, rowmap: RowMap, scale: float = 0.125):
+    """rows of q against the Lk keys of context rowmap(row); k / v: [ncontexts * Lk, heads * 64] (lkgd_hip.h section 15)"""
+    _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v"); _req(out, torch.float16, "out")
+    d1, m1, d2, md = rowmap[:4]
+    c0 = rowmap[4] if len(rowmap) > 4 else 0
+    check(_L().lkgd_attn_cross(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(), _ld(out),
+                               q.shape[0], heads, ncontexts, Lk, d1, m1, d2, md, c0, scale, _stream()), "lkgd_attn_cross")
+    return out
+
+
 def prepare_unet_input(latents: torch.Tensor, image_latents: torch.Tensor, cfg: int, sigma: float,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[B,F,4,H,W] latents (+ [cfg*B,F,4,H,W] image latents) -> channels-last tokens [cfg*B*F*H*W, 8]"""
@@ -421,15 +431,27 @@ def scale(x: torch.Tensor, s: float) -> torch.Tensor:
 
 
 def euler_step(model_output: torch.Tensor, sample: torch.Tensor, sigma: float, sigma_next: float,
-               v_prediction: bool = True) -> torch.Tensor:
+               v_prediction: bool = True, noise: torch.Tensor = None, sigma_hat: float = None, s_noise: float = 1.0,
+               churn: float = 0.0) -> torch.Tensor:
+    """one Euler step; with `noise` (fp16, same shape) the stochastic form: sample += fp16(fp16(noise * s_noise) * churn),
+    then the step from sigma_hat to sigma_next (lkgd_hip.h section 8)"""
     _req(model_output, torch.float16, "model_output")
     if not sample.is_cuda or sample.dtype not in (torch.float16, torch.float32):
         raise _lib.LkgdHipError("sample must be a GPU fp16/fp32 tensor")
     mo, sm = model_output.contiguous(), sample.contiguous()
     prev = torch.empty_like(mo)
-    check(_L().lkgd_euler_step(mo.data_ptr(), sm.data_ptr(), int(sm.dtype == torch.float32), prev.data_ptr(),
-                                     mo.numel(), sigma, sigma_next, 1 if v_prediction else 0, _stream()),
-          "lkgd_euler_step")
+    if noise is None:
+        check(_L().lkgd_euler_step(mo.data_ptr(), sm.data_ptr(), int(sm.dtype == torch.float32), prev.data_ptr(),
+                                   mo.numel(), sigma, sigma_next, 1 if v_prediction else 0, _stream()),
+              "lkgd_euler_step")
+        return prev
+    _req(noise, torch.float16, "noise")
+    if noise.numel() != mo.numel():
+        raise _lib.LkgdHipError("noise must have model_output's shape")
+    nz = noise.contiguous()
+    check(_L().lkgd_euler_step_churn(mo.data_ptr(), sm.data_ptr(), int(sm.dtype == torch.float32), nz.data_ptr(),
+                                     prev.data_ptr(), mo.numel(), sigma, sigma_hat, s_noise, churn, sigma_next,
+                                     1 if v_prediction else 0, _stream()), "lkgd_euler_step_churn")
     return prev
 
 

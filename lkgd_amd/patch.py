@@ -84,7 +84,11 @@ def collect_from_patch(model, attr="tome"):
 
 def initialize_joint_layers(model, post="conv", add_norm=False):
     if add_norm:
-        raise LkgdHipError("add_norm=True (AdaLayerNormContinuous norm1n) is not used by the SVD configs")
+        # reference patch.py:447-448 calls norm1n(norm_hidden_states, timestep); TransformerSpatioTemporalModel passes its
+        # blocks no timestep (None), so on the SVD UNet the reference's own add_norm forward cannot run - the option belongs
+        # to the image (UNet2DCondition) joint-diffusion models of utils/util.py:700-712, outside this path
+        raise LkgdHipError("add_norm=True (AdaLayerNormContinuous norm1n conditioned on `timestep`) does not apply to the "
+                           "SVD UNet: its transformer blocks receive no timestep")
     dm = _model(model)
     for _, m in _patched_blocks(model):
         m.attn1n = copy.deepcopy(m.attn1)

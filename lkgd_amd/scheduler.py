@@ -207,17 +207,30 @@ class EulerDiscreteScheduler:
         if not self.is_scale_input_called:
             logger.warning("The `scale_model_input` function should be called before `step` to ensure correct "
                            "denoising. See `StableDiffusionPipeline` for a usage example.")
-        if s_churn != 0.0:
-            raise NotImplementedError("s_churn > 0 (stochastic sampling) is outside the SVD hot path")
         if self._step_index is None:
             self._init_step_index(timestep)
         sigma, sigma_next = self.sigmas_host[self._step_index], self.sigmas_host[self._step_index + 1]
         pt = self.config.prediction_type
         if pt not in ("epsilon", "v_prediction"):
             raise ValueError(f"prediction_type given as {pt} must be one of `epsilon`, or `v_prediction`")
-        # NOTE: the reference draws randn here even with gamma == 0, advancing the global RNG;
-        # nothing downstream uses it, so it is not reproduced.
-        prev = ops.euler_step(model_output, sample, sigma, sigma_next, v_prediction=(pt == "v_prediction"))
+        gamma = min(s_churn / (len(self.sigmas_host) - 1), 2 ** 0.5 - 1) if s_tmin <= sigma <= s_tmax else 0.0
+        noise = None
+        if gamma > 0 or generator is not None:
+            # noise as randn_tensor draws it (model_output's dtype; a generator of another device draws on that device and the
+            # tensor is moved).  The reference draws at EVERY step, used or not: with a caller's generator that is observable
+            # (its state after the step), so it is drawn here too; the global RNG is left alone
+            gdev = generator.device if generator is not None else model_output.device
+            noise = torch.randn(model_output.shape, generator=generator, device=gdev, dtype=model_output.dtype)
+        if gamma > 0:
+            # stochastic step (reference :485-497), scalars in fp32 as the reference's 0-dim tensors
+            noise = noise.to(model_output.device)
+            sig = torch.tensor(sigma, dtype=torch.float32)
+            sig_hat = sig * (gamma + 1)
+            churn = float((sig_hat ** 2 - sig ** 2) ** 0.5)
+            prev = ops.euler_step(model_output, sample, sigma, sigma_next, v_prediction=(pt == "v_prediction"),
+                                  noise=noise, sigma_hat=float(sig_hat), s_noise=float(s_noise), churn=churn)
+        else:
+            prev = ops.euler_step(model_output, sample, sigma, sigma_next, v_prediction=(pt == "v_prediction"))
         self._step_index += 1
         if not return_dict:
             return (prev,)

@@ -100,6 +100,9 @@ class Ctx:
         self.entry_partner: Optional[List[int]] = None
         self.lora = None               # lkgd_amd.lora.EntryPlan when the model carries LoRA wrappers (masked LoRA forward)
         self.xb_runs: Optional[List[torch.Tensor]] = None     # cross-attention bias tables per entry run (LoRA on attn2)
+        # multi-token context (Lk > 1): the literal attn2 path (_cross_literal); xb_all is then a table of zeros
+        self.cross_Lk = 1
+        self.cross_e: Optional[torch.Tensor] = None       # [B_total * Lk, cross_attention_dim] fp16
 
     @property
     def frames_sharded(self) -> bool:
@@ -186,6 +189,14 @@ class Attention(nn.Module):
             bqkv = bqkv.contiguous()
         return SimpleNamespace(wqkv=pack_linear(w), bqkv=bqkv,
                                wo=pack_linear(_eff_weight(self.to_out[0], ao)), bo=_f32(self.to_out[0].bias))
+
+    def pack_cross(self, norm: nn.LayerNorm):
+        """literal cross-attention (context of more than one token): Q projection with the preceding LayerNorm folded in,
+        fused K|V projection of the context, out-projection"""
+        wq, bq = _fold_ln(norm, _eff_weight(self.to_q), None)
+        wkv = torch.cat([_eff_weight(self.to_k), _eff_weight(self.to_v)], dim=0)
+        return SimpleNamespace(wq=pack_linear(wq), bq=bq.contiguous(), wkv=pack_linear(wkv),
+                               wo=pack_linear(_eff_weight(self.to_out[0])), bo=_f32(self.to_out[0].bias))
 
     def fold_cross(self, adapters=((), ())):
         """single key/value token => attn2(x, e) == to_out(to_v(e)): returns (W_o @ W_v [C,1024] fp32, b_o); LoRA on
@@ -313,6 +324,27 @@ def _ff(ctx: Ctx, pk, x_norm: torch.Tensor, **epilogue) -> torch.Tensor:
     return out
 
 
+def _cross_literal(block, ctx: Ctx, h1: torch.Tensor, rowmap, first_ctx: int) -> torch.Tensor:
+    """attn2 as written (patch/patch.py:526-549, :660-668) for a context of Lk > 1 tokens: norm2 -> to_q; to_k | to_v of the
+    context tokens; every row against the Lk keys of the context `rowmap` selects (counted from entry `first_ctx`);
+    to_out + residual.  The one-token case never comes here (folded into a row bias by _cross_tables)."""
+    pk = block._pk
+    if not hasattr(pk, "x2"):
+        pk.x2 = block.attn2.pack_cross(block.norm2)
+    x2, (T, Cc), Lk = pk.x2, h1.shape, ctx.cross_Lk
+    ln2 = ops.layernorm(h1, None, None, 1e-5)
+    q = ctx.new(T, Cc)
+    ops.gemm(ln2, x2.wq, q, M=T, N=Cc, K=Cc, bias=x2.bq)
+    e = ctx.cross_e[first_ctx * Lk:]
+    kv = ctx.new(e.shape[0], 2 * Cc)
+    ops.gemm(e, x2.wkv, kv, M=e.shape[0], N=2 * Cc, K=e.shape[1])
+    att = ctx.new(T, Cc)
+    ops.attn_cross(q, kv[:, :Cc], kv[:, Cc:], att, block.attn2.heads, e.shape[0] // Lk, Lk, rowmap)
+    out = ctx.new(T, Cc)
+    ops.gemm(att, x2.wo, out, M=T, N=Cc, K=Cc, bias=x2.bo, res1=h1)
+    return out
+
+
 class BasicTransformerBlock(nn.Module):
     """spatial transformer block (witness patch/patch.py:390-580)"""
 
@@ -365,21 +397,24 @@ class BasicTransformerBlock(nn.Module):
                        N=Cc, K=Cc, rowmap=ops.rowmap_div(ctx.F * ctx.HW), res1=h)
             if self.enable_joint_attention and hasattr(self, "attn1n"):
                 h1 = self._joint(ctx, ln, h1)
-            ln3 = ops.layernorm(h1, None, None, 1e-5)
-            return _ff(ctx, pk.ff, ln3, res1=h1)
+            return self._tail(ctx, h1)
         if getattr(self, "_lkgd_fsm", False) and self.enable_joint_attention:
             # the track fuse reads attn1(x) + x BEFORE cross-attention: the folded attn2 bias is added by its last kernels
             ops.gemm(att, pk.a1.wo, h1, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=h)
-            h1 = self._fsm(ctx, h1)
-            ln3 = ops.layernorm(h1, None, None, 1e-5)
-            return _ff(ctx, pk.ff, ln3, res1=h1)
+            return self._tail(ctx, self._fsm(ctx, h1))
         # attn1 out-projection + residual + (attn2 == per-batch bias, norm2/Q/K are dead for one key token)
         ops.gemm(att, pk.a1.wo, h1, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=h,
                  rowbias=ctx.xb_all[ctx.b0:, pk.xoff:pk.xoff + Cc], rowmap=ops.rowmap_div(ctx.F * ctx.HW))
         if self.enable_joint_attention and hasattr(self, "attn1n"):
             h1 = self._joint(ctx, ln, h1)
+        return self._tail(ctx, h1)
+
+    def _tail(self, ctx: Ctx, h1: torch.Tensor) -> torch.Tensor:
+        """(literal attn2 for a multi-token context,) norm3 + feed-forward + residual"""
+        if ctx.cross_Lk > 1:
+            h1 = _cross_literal(self, ctx, h1, ops.rowmap_div(ctx.F * ctx.HW), ctx.b0)
         ln3 = ops.layernorm(h1, None, None, 1e-5)
-        return _ff(ctx, pk.ff, ln3, res1=h1)
+        return _ff(ctx, self._pk.ff, ln3, res1=h1)
 
     def _joint(self, ctx: Ctx, ln: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
         """joint attention attn1n with the partner batch entry's K/V (patch/patch.py:438-501); the post step
@@ -532,6 +567,8 @@ class TemporalBasicTransformerBlock(nn.Module):
                        N=Cc, K=Cc, rowmap=xmap, res1=m1)
         if self.enable_joint_attention and hasattr(self, "attn1n"):
             m2 = self._joint(ctx, ln1, m2)
+        if ctx.cross_Lk > 1:                  # literal attn2 over the time context (same row -> context map as the folded bias)
+            m2 = _cross_literal(self, ctx, m2, xmap, ctx.b0 if order == "batch_major" else 0)
         ln3 = ops.layernorm(m2, None, None, 1e-5)
         # ff(norm3(m2)) + m2, then AlphaBlender with the spatial branch - one epilogue
         return _ff(ctx, pk.ff, ln3, s_acc=1.0 - alpha, res1=m2, r1=1.0 - alpha, res2=h_s, r2=alpha)
@@ -1102,14 +1139,25 @@ class _UNetBase(nn.Module):
         ops.gemm(semb, pk.w_temb, ctx.temb_all, M=B, N=pk.w_temb.shape[0], K=pk.w_temb.shape[1], bias=pk.b_temb)
 
     def _cross_tables(self, ctx: Ctx, encoder_hidden_states: torch.Tensor) -> None:
-        if encoder_hidden_states.dim() != 3 or encoder_hidden_states.shape[1] != 1:
-            raise LkgdHipError("encoder_hidden_states must be [batch, 1, cross_attention_dim] (one CLIP image token); "
-                               "a multi-token context is outside the SVD hot path")
+        if encoder_hidden_states.dim() != 3:
+            raise LkgdHipError("encoder_hidden_states must be [batch, tokens, cross_attention_dim]")
         pk = self._pk
         if encoder_hidden_states.shape[0] != ctx.B_total:
             raise ValueError(f"encoder_hidden_states carries {encoder_hidden_states.shape[0]} entries, expected "
                              f"{ctx.B_total}")
         Bt = ctx.B_total       # under CFG sharding every rank still needs ALL contexts (App. C11 interleaving)
+        Lk = encoder_hidden_states.shape[1]
+        if Lk != 1:
+            # a multi-token context (never SVD's CLIP image token): attn2 runs as written, block by block (_cross_literal);
+            # the folded-bias epilogues of the blocks then add a table of zeros
+            if ctx.lora is not None:
+                raise LkgdHipError("masked LoRA with a multi-token context is not supported")
+            if Lk < 1 or Bt * Lk > 256:
+                raise LkgdHipError(f"context of {Bt} x {Lk} tokens: lkgd_attn_cross holds at most 256 key rows")
+            ctx.cross_Lk = Lk
+            ctx.cross_e = encoder_hidden_states.to(device=ctx.device, dtype=torch.float16).reshape(Bt * Lk, -1).contiguous()
+            ctx.xb_all = torch.zeros(Bt, pk.w_x.shape[0], dtype=torch.float16, device=ctx.device)
+            return
         e = encoder_hidden_states.to(device=ctx.device, dtype=torch.float16).reshape(Bt, -1).contiguous()
         ctx.xb_all = torch.empty(Bt, pk.w_x.shape[0], dtype=torch.float16, device=ctx.device)
         ops.gemm(e, pk.w_x, ctx.xb_all, M=Bt, N=pk.w_x.shape[0], K=pk.w_x.shape[1], bias=pk.b_x)

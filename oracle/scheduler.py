@@ -115,12 +115,18 @@ class EulerDiscreteOracle:
         sigma = self.sigmas[self._step_index]
         return sample / ((sigma ** 2 + 1) ** 0.5)
 
-    def step(self, model_output, t, sample):
+    def step(self, model_output, t, sample, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None):
+        """scheduling_euler_discrete_karras_fix.py:418-528; s_churn > 0 is the stochastic form (:485-497)"""
         if self._step_index is None:
             self._init_step_index(t)
         sample = sample.to(torch.float32)
         sigma = self.sigmas[self._step_index]
-        sigma_hat = sigma  # gamma == 0 (s_churn default 0)
+        gamma = min(s_churn / (len(self.sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigma <= s_tmax else 0.0
+        sigma_hat = sigma * (gamma + 1)
+        if gamma > 0 or generator is not None:      # the reference draws at every step; a caller's generator must advance alike
+            noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype)
+        if gamma > 0:
+            sample = sample + (noise * s_noise) * (sigma_hat ** 2 - sigma ** 2) ** 0.5
         pt = self.config.prediction_type
         if pt == "epsilon":
             x0 = sample - sigma_hat * model_output

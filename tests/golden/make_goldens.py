@@ -297,6 +297,34 @@ def gen_scheduler(sched_mod):
     print("scheduler: sigmas[25] head", out["cases"][2]["sigmas"][:3], "scalar", out["scalar_kat"])
 
 
+CHURN = dict(s_churn=20.0, s_tmin=0.05, s_tmax=200.0, s_noise=1.003)
+
+
+def gen_scheduler_churn(sched_mod):
+    """the stochastic step (s_churn > 0, scheduling_euler_discrete_karras_fix.py:485-497) of the reference scheduler over a
+    whole 25-step schedule of the SVD scheduler config (v_prediction), fp16 model outputs as on the GPU path; sigma > s_tmax
+    on the first steps (gamma = 0 there), gamma = sqrt(2) - 1 afterwards"""
+    from oracle.scheduler import SchedulerConfig
+    out = {"churn": CHURN, "cases": []}
+    for pt in ("v_prediction",):
+        cfg = dict(SchedulerConfig().__dict__, prediction_type=pt)
+        s = sched_mod.EulerDiscreteScheduler(**cfg)
+        s.set_timesteps(25)
+        g = torch.Generator().manual_seed(300)
+        gn = torch.Generator().manual_seed(301)          # the generator handed to step()
+        x = torch.randn(1, 2, 4, 3, 3, generator=g) * float(s.init_noise_sigma)
+        case = {"prediction_type": pt, "seed": 300, "noise_seed": 301, "x0": x.flatten().tolist(), "steps": []}
+        for t in s.timesteps:
+            v = torch.randn(x.shape, generator=g).half()
+            s.scale_model_input(x, t)
+            x = s.step(v, t, x, generator=gn, **CHURN).prev_sample
+            case["steps"].append({"v": v.float().flatten().tolist(), "prev": x.float().flatten().tolist()})
+        out["cases"].append(case)
+    with open(os.path.join(HERE, "scheduler_churn_kat.json"), "w") as f:
+        json.dump(out, f)
+    print("scheduler churn: last prev head", out["cases"][0]["steps"][-1]["prev"][:3])
+
+
 # ------------------------------------------------------------------------------------------------ 2. UNet wiring
 TINY = ou.TINY_CONFIG
 WSEED = 7
@@ -911,6 +939,10 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
     if only == "cogvideox":
         return gen_cogvideox()
+    if only == "scheduler_churn":
+        _mod("utils")
+        return gen_scheduler_churn(load_ref("utils/scheduling_euler_discrete_karras_fix.py",
+                                            "utils.scheduling_euler_discrete_karras_fix"))
     if only == "patch_lora":
         for m in ("models", "utils"):
             _mod(m)
@@ -962,6 +994,7 @@ def main():
         return
     sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
     gen_scheduler(sched_mod)
+    gen_scheduler_churn(sched_mod)
     ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
                          "models.unet_spatio_temporal_condition_controlnet")
     ref_lk = load_ref("models/unet_spatio_temporal_condition.py", "models.unet_spatio_temporal_condition")

@@ -607,6 +607,32 @@ def test_gemm_wide_rows_through_lds_match_direct_stores():
         L.lkgd_debug_set_wide_lds_out(-1)
 
 
+def test_attn_cross_short_contexts():
+    """lkgd_attn_cross: every row against the Lk keys of the context its row map selects (block-constant and interleaved
+    maps, a table that starts at a later context, ragged T) vs fp32 softmax attention"""
+    from lkgd_amd import ops
+    g = torch.Generator().manual_seed(31)
+    for T, heads, NC, Lk, rowmap, ld in [(700, 2, 3, 5, (250, 1, 1, 1 << 30), 128), (513, 3, 2, 77, (1 << 20, 0, 2, 2), 200),
+                                         (300, 1, 4, 1, (60, 7, 1, 4, 2), 64), (40, 5, 2, 128, (16, 1, 1, 2), 320)]:
+        C = heads * 64
+        q = _h(torch.randn(T, ld, generator=g))
+        k, v = _h(torch.randn(NC * Lk, ld, generator=g)), _h(torch.randn(NC * Lk, ld, generator=g))
+        d1, m1, d2, md = rowmap[:4]
+        c0 = rowmap[4] if len(rowmap) > 4 else 0
+        rows = torch.arange(T)
+        idx = ((rows // d1) * m1 + rows % d2 + c0) % md
+        kk = k[:, :C].float().reshape(NC, Lk, heads, 64)[idx]           # [T, Lk, heads, 64]
+        vv = v[:, :C].float().reshape(NC, Lk, heads, 64)[idx]
+        sc = torch.einsum("thd,tjhd->thj", q[:, :C].float().reshape(T, heads, 64), kk) * 0.125
+        ref = torch.einsum("thj,tjhd->thd", sc.softmax(-1), vv).reshape(T, C)
+        out = torch.full((T, ld), -3.0, dtype=torch.float16, device=DEV)
+        ops.attn_cross(q.to(DEV)[:, :C], k.to(DEV)[:, :C], v.to(DEV)[:, :C], out[:, :C], heads, NC, Lk, rowmap)
+        _close(out[:, :C], ref, what=f"attn_cross T={T} Lk={Lk}")
+        assert (out[:, C:] == -3).all()
+    with pytest.raises(Exception):          # a row map that reaches a context the table does not hold
+        ops.attn_cross(q.to(DEV)[:, :C], k.to(DEV)[:, :C], v.to(DEV)[:, :C], out[:, :C], heads, 2, 128, (8, 1, 1, 1 << 30))
+
+
 def test_attn_spatial_fewer_queries_than_keys(ops):
     """lkgd_attn_spatial_qk: Sq query rows against S key rows per batch entry (a frame-sharded DiT rank)"""
     g = torch.Generator().manual_seed(9)

@@ -42,6 +42,27 @@ def test_scheduler_tables_and_steps(kat, idx):
         assert torch.equal(x.flatten(), torch.tensor(st["prev"]))
 
 
+def test_scheduler_stochastic_step(golden_dir):
+    """s_churn > 0 (scheduling_euler_discrete_karras_fix.py:485-497): the oracle against the reference's own 25 steps,
+    fp16 model outputs, caller's generator - bit-exact"""
+    with open(os.path.join(golden_dir, "scheduler_churn_kat.json")) as f:
+        ck = json.load(f)
+    for case in ck["cases"]:
+        s = EulerDiscreteOracle(SchedulerConfig(prediction_type=case["prediction_type"]))
+        s.set_timesteps(25)
+        gn = torch.Generator().manual_seed(case["noise_seed"])
+        x = torch.tensor(case["x0"]).reshape(1, 2, 4, 3, 3)
+        changed = 0
+        for t, st in zip(s.timesteps, case["steps"]):
+            v = torch.tensor(st["v"]).reshape(x.shape).half()
+            plain = s.step(v, t, x)
+            s._step_index -= 1
+            x = s.step(v, t, x, generator=gn, **ck["churn"])
+            assert torch.equal(x.float().flatten(), torch.tensor(st["prev"]))
+            changed += int(not torch.equal(plain, x))
+        assert 15 <= changed < 25          # gamma = 0 while sigma > s_tmax, sqrt(2) - 1 afterwards
+
+
 def test_scheduler_survey_kat(kat):
     # SURVEY.md 8a row a2 / 8c: values produced by the reference file itself
     c25 = [c for c in kat["cases"] if c["n"] == 25][0]

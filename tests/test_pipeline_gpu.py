@@ -76,6 +76,40 @@ def test_scheduler_api_vs_reference_kat(golden_dir):
         assert s.step_index == case["n"]
 
 
+def test_scheduler_stochastic_step_vs_reference(golden_dir):
+    """scheduler.step(..., s_churn > 0) on the HIP path against the reference's own steps (same CPU generator, so the same
+    noise): within one fp16 ulp of the reference's fp16 result at every one of the 25 steps; epsilon prediction against the
+    oracle"""
+    from lkgd_amd.scheduler import EulerDiscreteScheduler
+    from oracle.scheduler import EulerDiscreteOracle, SchedulerConfig
+    with open(os.path.join(golden_dir, "scheduler_churn_kat.json")) as f:
+        ck = json.load(f)
+    case = ck["cases"][0]
+    s = EulerDiscreteScheduler(**SchedulerConfig().__dict__)
+    s.set_timesteps(25, device=DEV)
+    gn = torch.Generator().manual_seed(case["noise_seed"])
+    x = torch.tensor(case["x0"]).reshape(1, 2, 4, 3, 3).to(DEV)
+    for t, st in zip(s.timesteps, case["steps"]):
+        v = torch.tensor(st["v"]).reshape(x.shape).half().to(DEV)
+        prev = s.step(v, t, x, generator=gn, **ck["churn"]).prev_sample
+        ref = torch.tensor(st["prev"]).half()
+        ulp = (ref.float().abs() * 2.0 ** -10).clamp_min(2.0 ** -24)
+        assert ((prev.float().cpu().flatten() - ref.float()).abs() <= ulp).all()
+        x = ref.reshape(x.shape).to(DEV)                  # teacher-forced: the reference's fp16 sample
+    # epsilon prediction (not an SVD configuration): one stochastic step against the oracle
+    cfg = SchedulerConfig(prediction_type="epsilon")
+    o, h = EulerDiscreteOracle(cfg), EulerDiscreteScheduler(**cfg.__dict__)
+    o.set_timesteps(10), h.set_timesteps(10, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 3, 8, 8, generator=g) * float(o.init_noise_sigma)
+    v = torch.randn(x0.shape, generator=g).half()
+    for k in range(3):
+        t_o, t_h = o.timesteps[k], h.timesteps[k]
+        ref = o.step(v, t_o, x0, s_churn=8.0, s_noise=0.9, generator=torch.Generator().manual_seed(9 + k))
+        got = h.step(v.to(DEV), t_h, x0.to(DEV), s_churn=8.0, s_noise=0.9, generator=torch.Generator().manual_seed(9 + k)).prev_sample
+        assert (got.float().cpu() - ref.float()).abs().max() <= 2.0 ** -9 * ref.float().abs().max()
+
+
 def test_lk_loop_vs_oracle():
     """C3 path: LKGD UNet with domain/flow features, fuse hoisted out of the loop"""
     from lkgd_amd.pipeline import StableVideoDiffusionPipeline

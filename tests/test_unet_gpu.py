@@ -102,6 +102,38 @@ def test_time_context_order_switch(wiring):
         _gate(out, ref, f"time_context_order={order}")
 
 
+def test_multi_token_context_literal_cross_attention(wiring):
+    """a context of more than one token (never SVD's single CLIP token): attn2 runs as written (patch/patch.py:526-549,
+    :660-668) through lkgd_attn_cross instead of the folded row bias; both context row orders, with and without the joint
+    branch in front of it.  (diffusers 0.27.2 itself hard-codes one token in its interleaved broadcast; the oracle's
+    interleaved form with Lk > 1 is the natural extension.)"""
+    from oracle import blocks as ob
+    g = wiring
+    o, m = _pair(False, WSEED)
+    gg = torch.Generator().manual_seed(21)
+    enc = torch.randn(2, 3, 1024, generator=gg).half().float()
+    for order in ("batch_major", "interleaved_0_27"):
+        for mod in o.modules():
+            if isinstance(mod, ob.TransformerSpatioTemporalModel):
+                mod.time_context_order = order
+        for mod in m.modules():
+            if type(mod).__name__ == "TransformerSpatioTemporalModel":
+                mod.time_context_order = order
+        with torch.no_grad():
+            ref = o(g["in_sample"], g["in_t"], enc, added_time_ids=g["in_ids"], return_dict=False)[0]
+            one = o(g["in_sample"], g["in_t"], enc[:, :1], added_time_ids=g["in_ids"], return_dict=False)[0]
+        out = m(g["in_sample"].to(DEV), g["in_t"].to(DEV), enc.to(DEV), added_time_ids=g["in_ids"].to(DEV),
+                return_dict=False)[0]
+        _gate(out, ref, f"3-token context, {order}")
+        assert ((ref - one).norm() / ref.norm()).item() > 1e-2       # the extra tokens matter
+    # the one-token call on the same model still takes the folded path and matches
+    out1 = m(g["in_sample"].to(DEV), g["in_t"].to(DEV), enc[:, :1].to(DEV), added_time_ids=g["in_ids"].to(DEV),
+             return_dict=False)[0]
+    _gate(out1, one, "one-token context after a multi-token call")
+    with pytest.raises(Exception, match="256 key rows"):
+        m(g["in_sample"].to(DEV), g["in_t"].to(DEV), torch.randn(2, 200, 1024).to(DEV), added_time_ids=g["in_ids"].to(DEV))
+
+
 def test_odd_shapes_frames_and_rect(wiring):
     """ragged cases: 3 frames, non-square 8x16 latent (S = 128, 32, 8, 2 tokens at the four levels)"""
     o, m = _pair(False, 3)
