@@ -4,9 +4,19 @@
 
 // rows of one sample handled by one workgroup: ~32 KiB of activations per workgroup, so that small feature maps still
 // spread over all 256 CUs (18x32 @ 1280 channels: 12 rows -> 1344 workgroups instead of 252)
+static int gn_apply_kb = 32;
+extern "C" void lkgd_debug_set_gn_apply_kb(int kb) { gn_apply_kb = kb < 32 ? 32 : kb; }
 static inline int gn_rows(int C) {
-  int r = 32768 / (C * 2);
-  return r < 8 ? 8 : (r > 64 ? 64 : r);
+  int r = gn_apply_kb * 1024 / (C * 2);
+  return r < 8 ? 8 : (r > 1024 ? 1024 : r);
+}
+// the statistics pass may use longer chunks than the apply pass (fewer, larger workgroups; the partial buffer is sized for
+// the apply pass's chunk count, which is never smaller)
+static int gn_stats_kb = 128;
+extern "C" void lkgd_debug_set_gn_stats_kb(int kb) { gn_stats_kb = kb < 32 ? 32 : kb; }
+static inline int gn_rows_stats(int C) {
+  int r = gn_stats_kb * 1024 / (C * 2);
+  return r < 8 ? 8 : (r > 1024 ? 1024 : r);
 }
 #define GN_GROUPS 32
 #define GN_MAXC 4096
@@ -186,8 +196,9 @@ static int gn_check(const void* x0, int c0, int ld0, const void* x1, int c1, int
   return LKGD_OK;
 }
 
-extern "C" int lkgd_groupnorm_chunks(int64_t rows_per_sample, int32_t C) {
-  const int r = gn_rows(C);
+extern "C" int lkgd_groupnorm_chunks(int64_t rows_per_sample, int32_t C) {   // sizes the caller's `partial` scratch
+  const int ra = gn_rows(C), rs = gn_rows_stats(C);
+  const int r = ra < rs ? ra : rs;
   return (int)((rows_per_sample + r - 1) / r);
 }
 
@@ -197,10 +208,11 @@ extern "C" int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, con
   int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
   if (rc) return rc;
   if (!partial || !stats) return LKGD_E_NULL;
-  int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
+  const int rs = gn_rows_stats(c0 + c1);
+  int nchunks = (int)((rows_per_sample + rs - 1) / rs);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
-                     nchunks, gn_rows(c0 + c1));
+                     nchunks, rs);
   double inv = 1.0 / ((double)rows_per_sample * (double)((c0 + c1) / GN_GROUPS));
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
                      nchunks, inv, eps, stats);
@@ -213,10 +225,11 @@ extern "C" int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, cons
   int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
   if (rc) return rc;
   if (!partial || !sums) return LKGD_E_NULL;
-  int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
+  const int rs = gn_rows_stats(c0 + c1);
+  int nchunks = (int)((rows_per_sample + rs - 1) / rs);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
-                     nchunks, gn_rows(c0 + c1));
+                     nchunks, rs);
   hipLaunchKernelGGL(gn_sums_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial, nchunks,
                      sums);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
@@ -240,7 +253,8 @@ extern "C" int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, con
   if (rc) return rc;
   if (!stats || !gamma || !beta || !out) return LKGD_E_NULL;
   if (ldo % 8 || !aligned16(out)) return LKGD_E_ALIGN;
-  int nchunks = lkgd_groupnorm_chunks(rows_per_sample, c0 + c1);
+  const int ra = gn_rows(c0 + c1);
+  int nchunks = (int)((rows_per_sample + ra - 1) / ra);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, stats, gamma,
                      beta, silu, (half_t*)out, ldo, gn_rows(c0 + c1));
