@@ -11,7 +11,9 @@
 //   2. thread (pair p, query frame fq) loads ITS query row straight into registers and computes its 64-wide output row:
 //      K/V rows are shared by the query threads of a pair (LDS broadcast); scores by v_dot2_f32_f16, softmax in
 //      registers (exp2 with the scale folded in), P.V in fp32;
-//   3. the output row (128 contiguous bytes per thread) is stored directly.
+//   3. output rows leave through the (dead) K planes in LDS and are written plane by plane, 1 KiB contiguous per wave
+//      instruction (stored directly, a wave instruction was 64 x 16 bytes at a 128-byte stride: 5-7 % slower at the 72x128 and
+//      36x64 levels).  Staging the query planes through LDS as well costs two workgroups per CU and is slower (214 vs 171 us).
 // 28 KiB of LDS per workgroup at F = 14 -> five workgroups per CU keep loads, arithmetic and stores of different
 // workgroups overlapped.
 #include "common.h"
@@ -128,16 +130,33 @@ __global__ __launch_bounds__(FMAX * TP) void attn_temporal_kernel(const half_t* 
         }
       }
     }
-    // ---- 3. the output row: 128 contiguous bytes per thread
-    if (pair_ok) {
-      half_t* op = out + (((long long)b * Fq + fq) * S + my_s) * ldo + my_h * 64;
+  }
+  // ---- 3. output rows through LDS.  A thread owns one 128-byte row; stored directly, a wave instruction would write 64
+  //      16-byte pieces at a 128-byte stride (a CU sustains well under 16 GB/s of such stores, tools/micro/store_bw.hip).
+  //      The K planes are dead once every thread has its scores: each thread parks its row there (same XOR swizzle as K),
+  //      and the waves write whole (frame, 8 pairs) planes - 1 KiB contiguous per instruction when the rows are.
+  __syncthreads();
+  if (fq < Fq) {
+    char* orow = sk + fq * plane + pp * TROW;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        half8_t ov;
+    for (int i = 0; i < 8; ++i) {
+      half8_t ov;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = (half_t)o[i * 8 + e];
-        *(half8_t*)(op + i * 8) = ov;
-      }
+      for (int e = 0; e < 8; ++e) ov[e] = (half_t)o[i * 8 + e];
+      *(half8_t*)(orow + ((i ^ pp) << 4)) = ov;
+    }
+  }
+  __syncthreads();
+  {
+    const int lane = t & 63, w = t >> 6;
+    constexpr int nw = NT / 64;
+    const int lp = lane >> 3, ls = lane & 7;
+    const long long pid = pid0 + lp;
+    if (pid < npairs) {
+      const int s = (int)(pid / heads), hh = (int)(pid - (long long)s * heads);
+      const long long ooff = (long long)s * ldo + hh * 64 + ((ls ^ lp) << 3);
+      for (int j = w; j < Fq; j += nw)
+        *(half8_t*)(out + ((long long)b * Fq + j) * S * ldo + ooff) = *(const half8_t*)(sk + j * plane + lane * 16);
     }
   }
 }
