@@ -329,23 +329,44 @@ static int gemm_variant_override = 0;
 extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 5) ? v : 0; }
 extern "C" void lkgd_debug_set_gemm_splitk(int on);
 
+// Split-K for the 256x320 kernel on problems whose tiles leave CUs idle (fewer tiles than CUs): EQUAL K slices (a divisor
+// c <= 8 of K / 64, slices of >= 10 K-tiles, K >= 48 K-tiles in all, partials within the caller's workspace) as virtual
+// tiles.  Of the legal c the one whose virtual tiles best fill the CU rounds they occupy wins (ties: fewer slices), if that
+// fill is >= 70 % and at least 15 points above the unsplit fill; 0 = none.  Measured per slice count
+// (tools/micro/ksplit_sweep.py, profiles/r02_gemm_ksplit_sweep.txt): 64 tiles (4032 x 1280) want 4 slices - 3x3 conv 0.272
+// unsplit / 0.122 at 3 / 0.114 at 4, temporal conv 0.104 / 0.062 / 0.060; 128 tiles (8064 rows, the 18x32 level of a
+// CFG-parallel rank) want 2 - 3x3 conv 0.274 -> 0.200, FF-out 0.135 -> 0.108; 36 tiles (a rank of 8) want 5-6 even at
+// 10-K-tile slices (temporal conv 0.046 vs 0.050 on 128x128 tiles); below 48 K-tiles the fp32 partials cost more than the idle
+// CUs (9216 x 640 x 1920: 0.046 split vs 0.039 on 128x128 tiles).
+static bool gemm_splitk_enabled = true;
+static int wide_ksplit_forced = 0;      // tools/micro/ksplit_sweep.py: force this slice count where it is legal
+extern "C" void lkgd_debug_set_wide_ksplit(int k) { wide_ksplit_forced = k < 0 ? 0 : k; }
+static int wide_split(const lkgd_gemm_desc* d, long long tiles_wide, int cus) {
+  if (d->geglu || !d->workspace || !aligned16(d->workspace)) return 0;
+  const int nk = d->K / BK;
+  if (wide_ksplit_forced) {
+    const int c = wide_ksplit_forced;
+    return (c >= 2 && nk % c == 0 && (long long)c * d->M * d->N * 4 <= d->workspace_bytes) ? c : 0;
+  }
+  if (!gemm_splitk_enabled || tiles_wide >= cus || nk < 48) return 0;
+  const double unsplit = (double)tiles_wide / cus;
+  int best = 0;
+  double best_fill = 0.0;
+  for (int c = 2; c <= 8 && c * 10 <= nk; ++c) {
+    if (nk % c || (long long)c * d->M * d->N * 4 > d->workspace_bytes) continue;
+    const long long vt = tiles_wide * c, rounds = (vt + cus - 1) / cus;
+    const double fill = (double)vt / (double)(rounds * cus);
+    if (fill > best_fill + 1e-9) { best_fill = fill; best = c; }
+  }
+  return (best_fill >= 0.70 && best_fill >= unsplit + 0.15) ? best : 0;
+}
+
+extern "C" void lkgd_debug_set_gemm_splitk(int on);
+
 // Split-K for the 256x320 kernel on few-row problems (< half the CUs get a tile): the smallest number of EQUAL K slices
 // (a divisor of K / 64 up to 8, slices of >= 16 K-tiles, partials within the caller's workspace) whose virtual tiles fill
 // >= 75 % of the CU rounds they occupy; 0 = none.  Measured (tools/micro/m8064.py): 4032 x 1280 3x3 conv 0.150 -> 0.115 ms,
 // FF-out (K = 5120) 0.084 -> 0.070; 2304 x 1280 conv 0.102 -> 0.092; thinner slices or fuller machines lose to 128x128 tiles.
-static bool gemm_splitk_enabled = true;
-static int wide_split(const lkgd_gemm_desc* d, long long tiles_wide, int cus) {
-  if (!gemm_splitk_enabled || d->geglu || !d->workspace || !aligned16(d->workspace) || tiles_wide * 2 >= cus) return 0;
-  const int nk = d->K / BK;
-  for (int c = 2; c <= 8 && c * 16 <= nk; ++c) {
-    if (nk % c) continue;
-    if ((long long)c * d->M * d->N * 4 > d->workspace_bytes) return 0;
-    const long long vt = tiles_wide * c, rounds = (vt + cus - 1) / cus;
-    if (vt * 4 >= rounds * cus * 3) return c;
-  }
-  return 0;
-}
-
 extern "C" void lkgd_debug_set_gemm_splitk(int on) { gemm_splitk_enabled = on != 0; }
 
 extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
@@ -399,12 +420,12 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     // K <= 320 projections at 258k rows: A read exactly once.  The 320 x 320 ones only when they carry a residual (its
     // row-coalesced epilogue wins there; without one the 256x320 kernel is ahead)
     pick = 5;
+  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->M >= 2048 && (wide_ks = wide_split(d, tiles_wide, cus)) >= 2) {
+    pick = 4;                                            // fewer tiles than CUs, deep K: 256x320 tiles over equal K slices
+                                                         // (the 9x16 level; the 18x32 / 36x64 levels of sharded ranks)
   } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->K >= 320 && tiles_wide * 2 >= cus - 16) {
     pick = 4;                                            // every N = 320 / 640 / 960 / 1280 / 1920 / 3840 shape of the model
-                                                         // whose 256x320 tiles fill at least half the CUs (also the 8064-row
-                                                         // 18x32 level of a CFG-parallel rank: 0.284 vs 0.334 ms on its 3x3 conv)
-  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->M >= 2048 && (wide_ks = wide_split(d, tiles_wide, cus)) >= 2) {
-    pick = 4;                                            // few rows, deep K: 256x320 tiles over equal K slices
+                                                         // whose 256x320 tiles fill at least half the CUs
   } else if (d->M < 12288) {
     wide_ks = 1;
     // the 9x16 level (M = 4032; also the 9216-row 36x64 level of a rank of 8): 256-row tilings leave most CUs idle; 128x128

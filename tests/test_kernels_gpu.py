@@ -499,27 +499,31 @@ def test_gemm_split_k_few_rows():
 def test_gemm_split_k_on_256x320_tiles():
     """few-row, deep-K problems on the 256x320 kernel: equal K slices as virtual tiles + the shared reduce pass (the 18x32 /
     9x16 levels of the model at 4032 / 2304 rows).  Same result as the unsplit kernel up to fp32 summation order; a slice may
-    start in the middle of a (tap, source) segment of the implicit convolution."""
+    start in the middle of a (tap, source) segment of the implicit convolution.  The slice count is forced
+    (lkgd_debug_set_wide_ksplit) so that the case does not depend on the dispatcher's fill rule, which has its own checks below."""
     from lkgd_amd import _lib, ops
     from lkgd_amd.packing import pack_conv3x3
     L = _lib.lib()
     g = torch.Generator().manual_seed(23)
-    # plain: 12288 x 640 x 2048 -> 96 tiles, two slices of 16 K-tiles
-    M, N, K = 12288, 640, 2048
+    # plain: 12000 x 640 x 2048 -> 94 tiles, two slices of 16 K-tiles (ops.gemm hands a workspace to problems below 12288 rows)
+    M, N, K = 12000, 640, 2048
     a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
     b = torch.randn(N, generator=g)
     res = _h(torch.randn(M, N, generator=g))
     rows = torch.arange(0, M, 53)
     ref = a[rows].float() @ w.float().T + b + 0.5 * res[rows].float()
     outs = []
-    for on in (1, 0):
-        L.lkgd_debug_set_gemm_splitk(on)
+    L.lkgd_debug_set_gemm_variant(4)
+    for ks in (2, 0):
+        L.lkgd_debug_set_wide_ksplit(ks)
+        L.lkgd_debug_set_gemm_splitk(1 if ks else 0)
         out = torch.empty(M, N, dtype=torch.float16, device=DEV)
         ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=b.to(DEV), res1=res.to(DEV), r1=0.5)
         outs.append(out.cpu())
     L.lkgd_debug_set_gemm_splitk(1)
     _close(outs[0][rows], ref, what="256x320 split-K plain")
     assert (outs[0].float() - outs[1].float()).abs().max().item() <= 4e-3 * ref.abs().max().item()
+    assert not torch.equal(outs[0], outs[1])        # another fp32 summation order: the sliced path really ran
     # 3x3 conv, two sources (the slice boundary falls inside a tap): 3 images of 64x64, 128 + 128 channels -> K = 2304
     Nimg, C0, C1, Cout, H, W = 3, 128, 128, 320, 64, 64
     x0, x1 = _h(torch.randn(Nimg, C0, H, W, generator=g)), _h(torch.randn(Nimg, C1, H, W, generator=g))
@@ -527,16 +531,28 @@ def test_gemm_split_k_on_256x320_tiles():
     bc = torch.randn(Cout, generator=g)
     refc = F.conv2d(torch.cat([x0, x1], 1).float(), wc.float(), bc, padding=1)
     outs = []
-    for on in (1, 0):
-        L.lkgd_debug_set_gemm_splitk(on)
+    for ks in (2, 0):
+        L.lkgd_debug_set_wide_ksplit(ks)
+        L.lkgd_debug_set_gemm_splitk(1 if ks else 0)
         out = torch.empty(Nimg * H * W, Cout, dtype=torch.float16, device=DEV)
         ops.gemm(_tokens(x0).to(DEV), pack_conv3x3(wc).to(DEV), out, M=Nimg * H * W, N=Cout, K=9 * (C0 + C1),
                  a1=_tokens(x1).to(DEV), csplit=C0, bias=bc.to(DEV), mode=ops.A_CONV3X3, Cin=C0 + C1,
                  conv=(H, W, H, W, 1, 0))
         outs.append(out.cpu())
     L.lkgd_debug_set_gemm_splitk(1)
+    L.lkgd_debug_set_wide_ksplit(0)
+    L.lkgd_debug_set_gemm_variant(0)
     _close(_untokens(outs[0], Nimg, H, W), refc, what="256x320 split-K conv3x3")
     assert (outs[0].float() - outs[1].float()).abs().max().item() <= 4e-3 * refc.abs().max().item()
+    # the dispatcher's own choices (fill rule of wide_split): 4032 x 1280 x 3840 (64 tiles -> 4 slices), 8064 rows (128 tiles
+    # -> 2 slices), 2304 rows (36 tiles -> 6 slices of 10 K-tiles): against fp32 on sampled rows
+    for M, N, K in ((4032, 1280, 3840), (8064, 1280, 3840), (2304, 1280, 3840)):
+        a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+        b = torch.randn(N, generator=g)
+        rows = torch.arange(0, M, 37)
+        out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=b.to(DEV))
+        _close(out.cpu()[rows], a[rows].float() @ w.float().T + b, what=f"auto split {M}x{N}x{K}")
 
 
 def test_gemm_wide_rows_through_lds_match_direct_stores():
