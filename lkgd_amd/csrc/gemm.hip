@@ -416,11 +416,14 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     pick = 4;                                                         // 80-wide GEGLU interleave exists only in the 256x320 kernel
   } else if (v != 0) {
     pick = v;
-  } else if (rp_ok && d->M >= 4096 && d->K >= 192 && (d->N != 320 || d->res1)) {
+  } else if (rp_ok && d->M >= 4096 && d->K >= 192 && (d->res1 || (d->N != 320 && d->M >= 196608))) {
     // K <= 320 projections at 258k rows: A read exactly once.  The 320 x 320 ones only when they carry a residual (its
-    // row-coalesced epilogue wins there; without one the 256x320 kernel is ahead)
+    // row-coalesced epilogue wins there; without one the 256x320 kernel is ahead).  Without a residual (QKV) the two
+    // programs tie at 258k rows since the 256x320 kernel writes its rows through LDS, and at a sharded rank's row counts
+    // (129k / 65k / 37k: 504 / 252 / 144 row panels for 256 CUs) the 256x320 tiles fill the CUs better: 0.118 vs 0.125,
+    // 0.039 vs 0.052 ms (profiles/r02_gemm_shapes_ab_shards.txt)
     pick = 5;
-  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->M >= 2048 && (wide_ks = wide_split(d, tiles_wide, cus)) >= 2) {
+  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->M >= 1024 && (wide_ks = wide_split(d, tiles_wide, cus)) >= 2) {
     pick = 4;                                            // fewer tiles than CUs, deep K: 256x320 tiles over equal K slices
                                                          // (the 9x16 level; the 18x32 / 36x64 levels of sharded ranks)
   } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->K >= 320 && tiles_wide * 2 >= cus - 16) {

@@ -11,7 +11,9 @@ import torch
 from lkgd_amd import ops
 
 DEV = "cuda:0"
-N_IMG, B, F = 28, 2, 14
+# SHARD="B,F" (env): the shapes of ONE rank of a sharded run, e.g. "1,14" (rank of 2), "1,7" (of 4), "1,4" (of 8)
+B, F = (int(v) for v in os.environ.get("SHARD", "2,14").split(","))
+N_IMG = B * F
 LEVELS = [(72, 128, 320), (36, 64, 640), (18, 32, 1280), (9, 16, 1280)]
 
 
