@@ -409,6 +409,8 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
                        d->M < (1 << 24);
   const bool stream_ok = rows16 && d->geglu != 80;
   const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
+  // N tiles by 320 with at most a fifth of all tile columns idle (N = 256, 512, 768, 1536 ...)
+  const bool n320 = d->N % 320 == 0 || (long long)((d->N + 319) / 320) * 320 * 4 <= (long long)d->N * 5;
   int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide (256x320), 5 = rowpanel
   int wide_ks = 1;
   if (d->geglu == 80) {
@@ -426,9 +428,11 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->M >= 1024 && (wide_ks = wide_split(d, tiles_wide, cus)) >= 2) {
     pick = 4;                                            // fewer tiles than CUs, deep K: 256x320 tiles over equal K slices
                                                          // (the 9x16 level; the 18x32 / 36x64 levels of sharded ranks)
-  } else if (wide_ok && d->geglu == 0 && d->N % 320 == 0 && d->K >= 320 && tiles_wide * 2 >= cus - 16) {
+  } else if (wide_ok && d->geglu == 0 && n320 && d->K >= 320 && tiles_wide * 2 >= cus - 16) {
     pick = 4;                                            // every N = 320 / 640 / 960 / 1280 / 1920 / 3840 shape of the model
-                                                         // whose 256x320 tiles fill at least half the CUs
+                                                         // whose 256x320 tiles fill at least half the CUs; also N = 256 / 512
+                                                         // (the VAE: 20 % of the tile columns idle, still 960-1060 vs 800-860
+                                                         // TFLOP/s on the streaming kernel, tools/micro/vae_shapes_bench.py)
   } else if (d->M < 12288) {
     wide_ks = 1;
     // the 9x16 level (M = 4032; also the 9216-row 36x64 level of a rank of 8): 256-row tilings leave most CUs idle; 128x128
