@@ -24,6 +24,11 @@
 #else
 #define WIDE_OUT_ROW(m) (m)
 #endif
+#ifdef WIDE_X_SMALLA            /* the A operand comes from the first 4096 rows only: it stays L2-resident */
+#define WIDE_A_ROW(m) ((m) & 4095)
+#else
+#define WIDE_A_ROW(m) (m)
+#endif
 #ifdef WIDE_X_NT
 #define WIDE_ST(ptr, v) __builtin_nontemporal_store(v, ptr)
 #else
@@ -187,7 +192,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
         supertile<4>(st_tile / ksplit, tiles_m, tiles_n, tm, tn);
         st_k0 = SPLIT ? (st_tile % ksplit) * nk : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ag.rd[i] = lean_row<MODE>(p, tm * WBM + srow + 64 * i, rcp0, rcp1);
+        for (int i = 0; i < 4; ++i) ag.rd[i] = lean_row<MODE>(p, WIDE_A_ROW(tm * WBM) + srow + 64 * i, rcp0, rcp1);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
           int n = tn * WBN + srow + 64 * i;
