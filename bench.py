@@ -341,6 +341,8 @@ def main():
         img = torch.stack([img[0], img[0], img[1], 0.8 * img[1]])        # [u1, u2, c1, c2]
         emb = torch.stack([emb[0], emb[0], emb[1], 0.8 * emb[1]])
         ids = ids[:1].repeat(4, 1)
+        if dom is not None:                        # one feature row per batch entry [u1, u2, c1, c2]
+            dom, flow = torch.cat([dom, 0.7 * dom] * 2), torch.cat([flow, 0.6 * flow] * 2)
     ctrl_cond = None
     if args.controlnet:
         from lkgd_amd import controlnet as pc
