@@ -16,6 +16,8 @@
 // timing-experiment knobs (tools/micro/wide_knobs.sh; results are wrong with NOSTORE): never defined in the product build
 #ifdef WIDE_X_NOSTORE
 #define WIDE_STORE_GUARD if (p.ldc < 0)
+#elif defined(WIDE_X_ONELANE)   /* every store instruction is issued, one lane of it active: the epilogue's arithmetic without its bytes */
+#define WIDE_STORE_GUARD if ((threadIdx.x & 63) == 0)
 #else
 #define WIDE_STORE_GUARD
 #endif

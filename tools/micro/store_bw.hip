@@ -23,6 +23,13 @@ __global__ __launch_bounds__(512) void store_loop(_Float16* out, long long rows_
 #pragma unroll
       for (int i = 0; i < 20; ++i) *(half4*)(p + i * 16) = v4;       // 320 columns
     }
+  } else if (MODE == 2) {     // accumulator layout after a lane-pair exchange: 16 bytes per lane, 64 contiguous bytes per row and instruction
+    const int l15 = lane & 15, lq = lane >> 4;
+    for (long long r0 = 0; r0 < rows_per_wg; r0 += 128) {
+      _Float16* p = base + (r0 + w * 16 + l15) * ldc + (lq & 1) * 16 + (lq >> 1) * 8;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) *(half8*)(p + i * 32) = v8;       // 320 columns
+    }
   } else {                    // wave w: rows [r0 + w*16, +16) as 16-byte pieces, 40 pieces per 320-column row
     for (long long r0 = 0; r0 < rows_per_wg; r0 += 128) {
 #pragma unroll
@@ -39,20 +46,21 @@ int main() {
   const long long total_rows = 256LL * 4096;      // 640 MiB
   _Float16* out; hipMalloc(&out, total_rows * ldc * 2);
   hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
-  for (int mode = 0; mode < 2; ++mode)
+  for (int mode = 0; mode < 3; ++mode)
     for (int G : {16, 32, 64, 128, 256, 512, 1024}) {
       long long rows = total_rows / 1024;          // every grid writes the same bytes per workgroup
       float best = 1e9;
       for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(s);
         if (mode == 0) hipLaunchKernelGGL(store_loop<0>, dim3(G), dim3(512), 0, 0, out, rows, ldc);
-        else hipLaunchKernelGGL(store_loop<1>, dim3(G), dim3(512), 0, 0, out, rows, ldc);
+        else if (mode == 1) hipLaunchKernelGGL(store_loop<1>, dim3(G), dim3(512), 0, 0, out, rows, ldc);
+        else hipLaunchKernelGGL(store_loop<2>, dim3(G), dim3(512), 0, 0, out, rows, ldc);
         hipEventRecord(e); hipEventSynchronize(e);
         float ms; hipEventElapsedTime(&ms, s, e);
         if (ms < best) best = ms;
       }
       double bytes = (double)G * rows * ldc * 2;
-      printf("%s  G %4d: %7.3f ms  %6.2f TB/s  = %6.1f GB/s per workgroup\n", mode ? "16-byte row pieces " : "8-byte acc layout   ", G, best,
+      printf("%s  G %4d: %7.3f ms  %6.2f TB/s  = %6.1f GB/s per workgroup\n", mode == 1 ? "16-byte row pieces " : mode == 2 ? "16-byte paired lanes" : "8-byte acc layout   ", G, best,
              bytes / best / 1e9, bytes / best / 1e6 / G);
     }
   return 0;
