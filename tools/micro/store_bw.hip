@@ -10,7 +10,8 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 template <int MODE>
-__global__ __launch_bounds__(512) void store_loop(_Float16* out, long long rows_per_wg, int ldc) {
+__global__ __launch_bounds__(512) void store_loop(_Float16* out, long long rows_per_wg, int ldc, int xcd_mask = 0xff) {
+  if (!((xcd_mask >> (blockIdx.x & 7)) & 1)) return;         // only the workgroups of some XCDs store (round-robin dispatch)
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   _Float16* base = out + (long long)blockIdx.x * rows_per_wg * ldc;
   half8 v8; half4 v4;
@@ -63,5 +64,21 @@ int main() {
       printf("%s  G %4d: %7.3f ms  %6.2f TB/s  = %6.1f GB/s per workgroup\n", mode == 1 ? "16-byte row pieces " : mode == 2 ? "16-byte paired lanes" : "8-byte acc layout   ", G, best,
              bytes / best / 1e9, bytes / best / 1e6 / G);
     }
+  // all CUs of 4 or 2 XCDs storing (16-byte row pieces): is the write limit the chip's or each XCD's?
+  for (int mask : {0xff, 0x0f, 0x55, 0x03, 0x01}) {
+    long long rows = total_rows / 1024;
+    float best = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipEventRecord(s);
+      hipLaunchKernelGGL(store_loop<1>, dim3(256), dim3(512), 0, 0, out, rows, ldc, mask);
+      hipEventRecord(e); hipEventSynchronize(e);
+      float ms; hipEventElapsedTime(&ms, s, e);
+      if (ms < best) best = ms;
+    }
+    int n = __builtin_popcount(mask) * 32;
+    double bytes = (double)n * rows * ldc * 2;
+    printf("XCD mask 0x%02x (%3d workgroups): %7.3f ms  %6.2f TB/s  = %6.1f GB/s per workgroup\n", mask, n, best, bytes / best / 1e9,
+           bytes / best / 1e6 / n);
+  }
   return 0;
 }
