@@ -321,12 +321,15 @@ static int check_desc(const lkgd_gemm_desc* d) {
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit);   // gemm_wide.hip
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
+extern "C" int lkgd_gemm_resw_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_resw.hip
+extern "C" int lkgd_gemm_resw_ok(const lkgd_gemm_desc* d, int cus);
 
 // tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128 ring,
 // 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320),
 // 5 = force the register-resident row-panel kernel where it applies (plain A, K <= 320),
+// 6 = force the resident-weight kernel where it applies (plain A, K <= 320, N % 160 == 0)
 static int gemm_variant_override = 0;
-extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 5) ? v : 0; }
+extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 6) ? v : 0; }
 extern "C" void lkgd_debug_set_gemm_splitk(int on);
 
 // Split-K for the 256x320 kernel on problems whose tiles leave CUs idle (fewer tiles than CUs): EQUAL K slices (a divisor
@@ -408,6 +411,8 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   const bool wide_ok = (d->geglu == 0 || (d->geglu == 80 && plain)) && d->mode != LKGD_A_CONV3X3_C8 &&
                        d->M < (1 << 24);
   const bool stream_ok = rows16 && d->geglu != 80;
+  // resident-weight kernel: a 160-row slab of W[N][K] in LDS per workgroup, every XCD runs all N / 160 slabs
+  const bool rw_ok = lkgd_gemm_resw_ok(d, cus) != 0;
   const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
   // N tiles by 320 with at most a fifth of all tile columns idle (N = 256, 512, 768, 1536 ...)
   const bool n320 = d->N % 320 == 0 || (long long)((d->N + 319) / 320) * 320 * 4 <= (long long)d->N * 5;
@@ -415,9 +420,18 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   int wide_ks = 1;
   if (d->geglu == 80) {
     if (!wide_ok) return LKGD_E_SHAPE;
-    pick = 4;                                                         // 80-wide GEGLU interleave exists only in the 256x320 kernel
+    // 80-wide GEGLU interleave: the 256x320 kernel, or - at K <= 320 from 32k rows - the resident-weight kernel (a slab = one
+    // wave's 160 packed rows): its waves run their erf epilogues beside each other's K-loops (72x128 level 0.485 vs 0.533 ms,
+    // a CFG-parallel rank's 0.246 vs 0.274; profiles/r03_resw_ab.txt)
+    pick = (rw_ok && (v == 6 || (v == 0 && d->M >= 32768))) ? 6 : 4;
   } else if (v != 0) {
     pick = v;
+  } else if (rw_ok && d->res1 && d->M >= 32768) {
+    // K <= 320 projections that carry a residual (attention out, proj_out at the 72x128 level): 0.125 ms against 0.138
+    // (row-panel) / 0.152 (256x320) at 258k rows, 0.053 vs 0.059 at 129k.  Without a residual the 256x320 kernel stays
+    // ahead (QKV 0.225 vs 0.264, bias-only 0.089 vs 0.096): there the resident-weight kernel's token loads (64 different
+    // rows per instruction) and its eight in-order waves do not hide what they wait for
+    pick = 6;
   } else if (rp_ok && d->M >= 4096 && d->K >= 192 && (d->res1 || (d->N != 320 && d->M >= 196608))) {
     // K <= 320 projections at 258k rows: A read exactly once.  The 320 x 320 ones only when they carry a residual (its
     // row-coalesced epilogue wins there; without one the 256x320 kernel is ahead).  Without a residual (QKV) the two
@@ -442,10 +456,12 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     pick = 3;
   }
   // applicability (forced variants fall back the same way)
+  if (pick == 6 && !rw_ok) pick = d->geglu == 80 ? 4 : 1;
   if (pick == 5 && !rp_ok) pick = 1;
   if (pick == 4 && !wide_ok) pick = 3;
   if (pick == 3 && (!stream_ok || d->M <= 256)) pick = (d->K >= 960 && d->M > 256) ? 2 : 1;
-  if (d->geglu == 80 && pick != 4) return LKGD_E_SHAPE;   // 80-wide interleave exists only in the 256x320 kernels
+  if (d->geglu == 80 && pick != 4 && pick != 6) return LKGD_E_SHAPE;   // 80-wide interleave: 256x320 / resident-weight kernels
+  if (pick == 6) return lkgd_gemm_resw_launch(d, (hipStream_t)stream, cus);
   if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
   if (pick == 4) {
     if (v == 4) wide_ks = wide_split(d, tiles_wide, cus);      // forced variant: same slicing rule

@@ -24,12 +24,13 @@ def _close(got, ref, rtol=4e-3, what=""):
     assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
 
 
-@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel"])
+@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel", "resw"])
 def ops(request):
     """every GEMM/conv test runs against ALL kernel variants (128x128 two-stage, 256x128 three-stage ring, persistent
-    streaming kernel with register epilogue)"""
+    streaming kernel with register epilogue, 256x320, row-panel, resident-weight; a forced variant falls back to the 128x128
+    program on shapes it does not cover)"""
     from lkgd_amd import _lib, ops
-    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5}[request.param])
+    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5, "resw": 6}[request.param])
     yield ops
     _lib.lib().lkgd_debug_set_gemm_variant(0)
 
@@ -662,3 +663,67 @@ def test_attn_spatial_fewer_queries_than_keys(ops):
     qf, kf, vf = (t.float().reshape(nb, -1, heads, 64).transpose(1, 2) for t in (q, k, v))
     ref = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(nb * Sq, C)
     assert (out.float() - ref).abs().max() < 4e-3
+
+
+def test_gemm_resident_weight_kernel():
+    """lkgd_gemm_resw_kernel (K <= 320, N % 160 == 0: a 160-channel weight slab resident in LDS, waves independent): every
+    epilogue source combination, ragged M (partial 32-row block, fewer blocks than waves, one row), 1 / 2 / 6 slabs,
+    K = 64 .. 320, GEGLU with the 80 | 80 interleave - against fp32, and bitwise against the 256x320 kernel where both apply"""
+    from lkgd_amd import _lib, ops
+    from lkgd_amd.packing import pack_geglu
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(606)
+    try:
+        for M, N, K in ((32 * 700 + 13, 320, 320), (1, 160, 64), (250, 960, 320), (32 * 40, 320, 128), (9000, 160, 256),
+                        (32 * 257 + 31, 640, 192)):
+            a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+            bias = torch.randn(N, generator=g)
+            r1, r2 = _h(torch.randn(M, N, generator=g)), _h(torch.randn(M, N, generator=g))
+            table = _h(torch.randn(7, N, generator=g))
+            idx = (torch.arange(M) // 100) % 7
+            acc = a.float() @ w.float().T
+            ad, wd = a.to(DEV), w.to(DEV)
+            for src in range(8):
+                kw, ref = {}, acc + bias
+                if src & 1:
+                    kw.update(rowbias=table.to(DEV), rowmap=ops.rowmap_div_mod(100, 7))
+                    ref = ref + table.float()[idx]
+                ref = 0.7 * ref
+                if src & 2:
+                    kw.update(res1=r1.to(DEV), r1=0.6)
+                    ref = ref + 0.6 * r1.float()
+                if src & 4:
+                    kw.update(res2=r2.to(DEV), r2=0.3)
+                    ref = ref + 0.3 * r2.float()
+                out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+                L.lkgd_debug_set_gemm_variant(6)
+                ops.gemm(ad, wd, out, M=M, N=N, K=K, bias=bias.to(DEV), s_acc=0.7, **kw)
+                _close(out, ref, what=f"resw {M}x{N}x{K} src {src}")
+                if N % 320 == 0 and K >= 64:
+                    out4 = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+                    L.lkgd_debug_set_gemm_variant(4)
+                    ops.gemm(ad, wd, out4, M=M, N=N, K=K, bias=bias.to(DEV), s_acc=0.7, **kw)
+                    assert torch.equal(out, out4), f"resw vs 256x320 {M}x{N}x{K} src {src}"
+            out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+            L.lkgd_debug_set_gemm_variant(6)
+            ops.gemm(ad, wd, out, M=M, N=N, K=K)                     # no bias, no sources (QKV)
+            _close(out, acc, what=f"resw bare {M}x{N}x{K}")
+        for M, C in ((700, 320), (32 * 300 + 5, 320), (40, 64)):
+            a = _h(torch.randn(M, C, generator=g))
+            w = torch.randn(8 * C, C, generator=g) / C ** 0.5
+            b = torch.randn(8 * C, generator=g) * 0.1
+            y = a.float() @ _h(w).float().T + b
+            hid, gate = y.chunk(2, dim=-1)
+            if (4 * C) % 80:
+                continue
+            wp, bp, half = pack_geglu(w, b, half=80)
+            out = torch.full((M, 4 * C), float("nan"), dtype=torch.float16, device=DEV)
+            L.lkgd_debug_set_gemm_variant(6)
+            ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=8 * C, K=C, bias=bp.to(DEV), geglu=half)
+            _close(out, hid * F.gelu(gate), what=f"resw geglu {M}x{C}")
+            out4 = torch.full((M, 4 * C), float("nan"), dtype=torch.float16, device=DEV)
+            L.lkgd_debug_set_gemm_variant(4)
+            ops.gemm(a.to(DEV), wp.to(DEV), out4, M=M, N=8 * C, K=C, bias=bp.to(DEV), geglu=half)
+            assert torch.equal(out, out4), f"resw geglu vs 256x320 {M}x{C}"
+    finally:
+        L.lkgd_debug_set_gemm_variant(0)

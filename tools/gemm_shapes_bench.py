@@ -74,7 +74,7 @@ def run(kind, d, iters=5, variants=None):
         geglu = kind == "geglu"
         out = torch.empty(M, N // 2 if geglu else N, device=DEV, dtype=torch.float16)
         bias = None if d.get("plain") else torch.zeros(N, device=DEV)
-        res = None if (geglu or d.get("plain") or os.environ.get('NORES')) else torch.zeros(M, N, device=DEV, dtype=torch.float16)
+        res = None if (geglu or d.get("plain") or d.get("nores") or os.environ.get('NORES')) else torch.zeros(M, N, device=DEV, dtype=torch.float16)
         from lkgd_amd.packing import geglu_half
         gw = [geglu_half(N, K)]       # interleave width; the forced 256x320 variant runs its own 80-wide packing
         fn = lambda: ops.gemm(a, w, out, M=M, N=N, K=K, bias=bias, geglu=gw[0] if geglu else 0, res1=res)   # noqa
@@ -99,7 +99,7 @@ def run(kind, d, iters=5, variants=None):
         for v in variants:
             _lib.lib().lkgd_debug_set_gemm_variant(v)
             if kind == "geglu":
-                gw[0] = 80 if v == 4 else (geglu_half(N, K) if v == 0 else 32)
+                gw[0] = 80 if v in (4, 6) else (geglu_half(N, K) if v == 0 else 32)
             try:
                 t = once()
             except Exception:          # variant not applicable to this shape
@@ -144,8 +144,8 @@ def main_ldsout():
 
 def main_ab():
     warm()
-    variants = [0, 1, 3, 4, 5]
-    names = {0: "auto", 1: "t128", 2: "t256", 3: "strm", 4: "wide", 5: "rowp"}
+    variants = [0, 1, 3, 4, 5, 6]
+    names = {0: "auto", 1: "t128", 2: "t256", 3: "strm", 4: "wide", 5: "rowp", 6: "resw"}
     print(f"{'shape':34s} {'cnt':>4s} " + " ".join(f"{names[v]:>8s}" for v in variants) + "   (ms per launch; * = best)")
     tot = {v: 0.0 for v in variants}
     tot_best = tot_f = 0.0
