@@ -10,7 +10,8 @@
  * Conventions
  *   - all pointers are DEVICE pointers unless named h_*; activations are fp16, channels-last:
  *     a "token matrix" [T, C] with T = (batch*frame, y, x) row-major, C contiguous.
- *   - no allocation, no synchronisation, no global state inside; safe on any stream; graph-capturable.
+ *   - no allocation, no synchronisation, no global state inside; safe on any stream; graph-capturable (the debug
+ *     knobs declared at the end of this file are the one exception and say so).
  *   - return value: 0 = launched; negative = LKGD_E_* (nothing was launched).
  */
 #ifndef LKGD_HIP_H
@@ -313,6 +314,30 @@ int lkgd_attn_cross(const void* q, int32_t ldq, const void* k, int32_t ldk, cons
 
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * DEBUG / MEASUREMENT KNOBS - not part of the reference-facing interface, NOT thread-safe.
+ *    Everything above keeps its promise of "no global state" only while none of these is called: each one writes a
+ *    process-global variable that every later launch of the op, on any thread and stream, reads.  They exist for the
+ *    A/B tools under tools/ and for the per-variant parity tests (tests/test_kernels_gpu.py); a product caller never
+ *    needs them.  Value 0 (or -1 where noted) restores the automatic behaviour.
+ *      lkgd_debug_set_gemm_variant(v)   force a tile program of lkgd_gemm_f16 where it applies: 1 = 128x128, 2 = 256x128 ring,
+ *                                       3 = persistent 256x128, 4 = 256x320, 5 = row-panel, 6 = resident-weight; 0 = auto
+ *      lkgd_debug_set_gemm_splitk(on)   0 = never cut K into slices
+ *      lkgd_debug_set_wide_ksplit(k)    force k K-slices on the 256x320 program where legal; 0 = rule
+ *      lkgd_debug_set_wide_lds_out(on)  256x320 program: 0 = direct 8-byte stores everywhere, 1 / -1 = rows through LDS where used
+ *      lkgd_debug_set_attn_waves(nw)    spatial attention: waves per workgroup (4 / 8 / 16); 0 = by sequence length
+ *      lkgd_debug_set_attn_kvb(kvb)     spatial attention: keys per barrier (64 / 128); 0 = default
+ *      lkgd_debug_set_gn_apply_kb(kb) / lkgd_debug_set_gn_stats_kb(kb)   GroupNorm chunk sizes in KiB (>= 32)
+ * ------------------------------------------------------------------------------------------------------------- */
+void lkgd_debug_set_gemm_variant(int32_t v);
+void lkgd_debug_set_gemm_splitk(int32_t on);
+void lkgd_debug_set_wide_ksplit(int32_t k);
+void lkgd_debug_set_wide_lds_out(int32_t on);
+void lkgd_debug_set_attn_waves(int32_t nw);
+void lkgd_debug_set_attn_kvb(int32_t kvb);
+void lkgd_debug_set_gn_apply_kb(int32_t kb);
+void lkgd_debug_set_gn_stats_kb(int32_t kb);
 
 #ifdef __cplusplus
 }

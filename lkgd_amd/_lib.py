@@ -90,6 +90,15 @@ SYMBOLS = {
     "lkgd_gelu_tanh": (_i32, [_vp, _vp, _i64, _vp]),
     "lkgd_gated_add": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "lkgd_version": (C.c_char_p, []),
+    # debug / measurement knobs (process-global, not thread-safe: include/lkgd_hip.h, last section)
+    "lkgd_debug_set_gemm_variant": (None, [_i32]),
+    "lkgd_debug_set_gemm_splitk": (None, [_i32]),
+    "lkgd_debug_set_wide_ksplit": (None, [_i32]),
+    "lkgd_debug_set_wide_lds_out": (None, [_i32]),
+    "lkgd_debug_set_attn_waves": (None, [_i32]),
+    "lkgd_debug_set_attn_kvb": (None, [_i32]),
+    "lkgd_debug_set_gn_apply_kb": (None, [_i32]),
+    "lkgd_debug_set_gn_stats_kb": (None, [_i32]),
 }
 
 _lib = None

@@ -225,8 +225,23 @@ class CogVideoXTransformer3DModel(nn.Module):
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, subfolder: Optional[str] = None, torch_dtype=None,
                         variant: Optional[str] = None, **_ignored):
-        from .loading import build_from_pretrained
+        from .loading import build_from_pretrained, load_config, load_state_dict
+        raw = load_config(pretrained_model_name_or_path, subfolder)
+        for key in ("use_rotary_positional_embeddings", "patch_size_t", "ofs_embed_dim"):
+            if raw.get(key):        # the 5B / 1.5 variants (rotary embeddings, temporal patches, ofs embedding) are not built
+                raise LkgdHipError(f"CogVideoXTransformer3DModel.from_pretrained: config has {key}={raw[key]!r}; only the "
+                                   "2B architecture (learned positional embedding, 2-D patches) is implemented")
+        # stock checkpoints have no quaternion_lora_* modules: those may be missing; anything else missing or unexpected
+        # (a truncated shard, renamed parameters) would leave meta-initialised garbage behind a non-strict load
+        sd_keys = set(load_state_dict(pretrained_model_name_or_path, subfolder, variant).keys())
         m = build_from_pretrained(cls, DiTConfig, pretrained_model_name_or_path, subfolder, torch_dtype, variant, strict=False)
+        own = set(m.state_dict().keys())
+        missing = sorted(k for k in own - sd_keys if not k.startswith("quaternion_lora_"))
+        unexpected = sorted(sd_keys - own)
+        if missing or unexpected:
+            raise RuntimeError(f"CogVideoXTransformer3DModel.from_pretrained({pretrained_model_name_or_path!r}): missing keys "
+                               f"{missing[:5]}{'...' if len(missing) > 5 else ''}, unexpected keys {unexpected[:5]}"
+                               f"{'...' if len(unexpected) > 5 else ''}")
         return m
 
     def save_pretrained(self, save_directory: str, variant: Optional[str] = None, **_ignored):

@@ -176,6 +176,10 @@ class ControlNetSDVModel(_UNetBase):
         self.prepare()
         ctx = Ctx(B, F, H, W, self.device, shard)
         pk = self._pk
+        if getattr(pk, "has_lora", False):
+            # the UNet builds a per-entry weight plan for wrapped projections (lkgd_amd/lora.py); this encoder does not, and
+            # running the packed base weights would drop the adapters silently
+            raise LkgdHipError("LoRA wrappers on the ControlNet are not applied by forward_tokens: lora.merge_lora() them first")
         self._time_embed(ctx, timestep, added_time_ids)
         self._cross_tables(ctx, encoder_hidden_states)
         c0 = pk.w_in.shape[0]

@@ -355,8 +355,11 @@ static int wide_split(const lkgd_gemm_desc* d, long long tiles_wide, int cus) {
   const double unsplit = (double)tiles_wide / cus;
   int best = 0;
   double best_fill = 0.0;
+  // measured tile counts: 36, 64, 128 (slices 5-6, 4, 2).  Elsewhere - e.g. ~200 tiles, where the fill rule would pick 5 - the
+  // partial traffic c * M * N * 4 bytes is kept within what the measured cases moved (4 slices at 64 tiles = 66 MB x 4)
   for (int c = 2; c <= 8 && c * 10 <= nk; ++c) {
     if (nk % c || (long long)c * d->M * d->N * 4 > d->workspace_bytes) continue;
+    if (tiles_wide > 128 && c > 2) continue;
     const long long vt = tiles_wide * c, rounds = (vt + cus - 1) / cus;
     const double fill = (double)vt / (double)(rounds * cus);
     if (fill > best_fill + 1e-9) { best_fill = fill; best = c; }
@@ -364,12 +367,6 @@ static int wide_split(const lkgd_gemm_desc* d, long long tiles_wide, int cus) {
   return (best_fill >= 0.70 && best_fill >= unsplit + 0.15) ? best : 0;
 }
 
-extern "C" void lkgd_debug_set_gemm_splitk(int on);
-
-// Split-K for the 256x320 kernel on few-row problems (< half the CUs get a tile): the smallest number of EQUAL K slices
-// (a divisor of K / 64 up to 8, slices of >= 16 K-tiles, partials within the caller's workspace) whose virtual tiles fill
-// >= 75 % of the CU rounds they occupy; 0 = none.  Measured (tools/micro/m8064.py): 4032 x 1280 3x3 conv 0.150 -> 0.115 ms,
-// FF-out (K = 5120) 0.084 -> 0.070; 2304 x 1280 conv 0.102 -> 0.092; thinner slices or fuller machines lose to 128x128 tiles.
 extern "C" void lkgd_debug_set_gemm_splitk(int on) { gemm_splitk_enabled = on != 0; }
 
 extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {

@@ -78,7 +78,10 @@ def make_plan(world: int, rank: int, num_frames: int, cfg: bool) -> ShardPlan:
     return ShardPlan(world, rank, cfg_groups, shards, ci, si, splits, sum(splits[:si]), num_frames)
 
 
-_HALO_ALLGATHER = __import__("os").environ.get("LKGD_HALO_ALLGATHER", "0") == "1"
+# Conv3d halo exchange: the all-gather form is the default until a multi-GPU RCCL run has compared both forms bitwise
+# (ADVICE r2); LKGD_HALO_P2P=1 selects the neighbour-only batch_isend_irecv exchange (2 frames in / out per rank instead of
+# 2(k-1) delivered), tests/test_dist_gpu.py checks the two forms against each other
+_HALO_ALLGATHER = __import__("os").environ.get("LKGD_HALO_P2P", "0") != "1"
 
 
 def _backend(group) -> str:
@@ -141,10 +144,10 @@ def exchange_halo(buf: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tenso
     shard's last frame and slot f_local + 1 with the next shard's first one.  At the ends of the clip the slot is left as
     the caller allocated it (zeros = the Conv3d's zero padding).
 
-    Neighbour-only exchange: each rank sends its first frame to shard i-1 and its last frame to shard i+1 and receives the
-    two it needs (``batch_isend_irecv`` - point-to-point over the one xGMI link to each neighbour), i.e. 2 frames in, 2
-    frames out per rank whatever the shard count; an all-gather of boundary frames would deliver 2(k-1) frames to every
-    rank, 6 of which a rank of 8 (k = 4) throws away.  LKGD_HALO_ALLGATHER=1 keeps that form as an A/B knob."""
+    Default: an all-gather of every shard's two boundary frames over the frame group (2(k-1) frames delivered to every
+    rank, 6 of them unused at k = 4).  LKGD_HALO_P2P=1: neighbour-only exchange - each rank sends its first frame to shard
+    i-1 and its last frame to shard i+1 and receives the two it needs (``batch_isend_irecv``, point-to-point over the one
+    xGMI link to each neighbour); opt-in until both forms have been compared on a multi-GPU RCCL world."""
     k, fl, si = plan.frame_shards, plan.f_local, plan.shard_index
     if k == 1:
         return buf

@@ -381,9 +381,15 @@ class StableVideoDiffusionPipeline:
             noise = _randn_tensor(img.shape, generator, device, img.dtype)      # drawn for the execution device (:467)
             img = img + noise_aug_strength * noise
             # reference :470-484: an fp16 VAE with `force_upcast` encodes in fp32 and is cast back right after (so the
-            # decode at the end runs in fp16 again, :643-645)
+            # decode at the end runs in fp16 again, :643-645).  The HIP VAE computes fp16 activations with fp32 accumulation
+            # whatever the module dtype says (lkgd_amd/vae.py), so casting it there and back would only re-pack its weights
+            # twice per call: the module is left alone, and what the upcast protects against - an fp16 overflow in the
+            # encoder - is checked instead (deviations)
             vae_dtype = getattr(self.vae, "dtype", None)
-            needs_upcasting = vae_dtype == torch.float16 and bool(getattr(self.vae.config, "force_upcast", False))
+            from .vae import AutoencoderKLTemporalDecoder
+            hip_vae = isinstance(self.vae, AutoencoderKLTemporalDecoder)
+            needs_upcasting = (not hip_vae and vae_dtype == torch.float16 and
+                               bool(getattr(self.vae.config, "force_upcast", False)))
             if needs_upcasting:
                 self.vae.to(dtype=torch.float32)
             elif vae_dtype is not None and vae_dtype != img.dtype:
@@ -392,6 +398,9 @@ class StableVideoDiffusionPipeline:
             image_latents = image_latents.to(image_embeddings.dtype)                                  # reference :480
             if needs_upcasting:
                 self.vae.to(dtype=torch.float16)
+            if hip_vae and not bool(torch.isfinite(image_latents).all()):
+                raise LkgdHipError("VAE encode produced non-finite latents (fp16 range exceeded in the encoder): the reference "
+                                   "encodes in fp32 under force_upcast; scale the input or encode outside and pass image_latents")
         image_latents = image_latents.to(device=device, dtype=torch.float16)
         if image_latents.dim() == 4:      # [cfg*B,4,h,w] -> repeat over frames (:488)
             image_latents = image_latents.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)

@@ -65,6 +65,22 @@ def _worker(rank, world, port, frames, q):
         exchange_halo(hb, plan)
         padded = torch.cat([torch.zeros(1, 3, 5), full, torch.zeros(1, 3, 5)])
         ok = ok and torch.equal(hb, padded[plan.f0:plan.f0 + plan.f_local + 2])
+        # both forms of the exchange (default all-gather of boundary frames, opt-in neighbour-only P2P) give the same buffer,
+        # also as recorded steps replayed on new values (P2P stays opt-in until compared on a multi-GPU RCCL world)
+        import lkgd_amd.dist as ld
+        from lkgd_amd import replay as _rp
+        for allgather in (True, False):
+            ld._HALO_ALLGATHER = allgather
+            hb2 = torch.zeros(plan.f_local + 2, 3, 5)
+            hb2[1:plan.f_local + 1] = local
+            with _rp.record() as rec_h:
+                exchange_halo(hb2, plan)
+            ok = ok and torch.equal(hb2, hb)
+            hb2[1:plan.f_local + 1] = 3.0 * local
+            rec_h.run()
+            want = 3.0 * padded[plan.f0:plan.f0 + plan.f_local + 2]
+            ok = ok and torch.equal(hb2, want)
+        ld._HALO_ALLGATHER = True
         # recorded exchange steps (lkgd_amd/replay.py): new values in the same buffers, same plan
         from lkgd_amd import replay
         src = local.clone()

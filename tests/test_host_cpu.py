@@ -236,3 +236,25 @@ def test_controlnet_condition_cache_owns_its_key():
         assert c._cond_tokens(cond, 2, 4, 8, 8) is t
         del cond, t
     assert len(calls) == 6
+
+
+def test_resident_weight_kernel_has_no_register_spills():
+    """lkgd_amd/csrc/gemm_resw.hip issues and awaits its epilogue loads by hand (inline asm, counted vmcnt): spill code
+    between a load and its wait would save a register whose data has not arrived.  Every instantiation the launcher can
+    pick must therefore be allocated without scratch spills inside its 96-register budget (hipcc cross-compiles here)."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    src = os.path.join(REPO, "lkgd_amd", "csrc", "gemm_resw.hip")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", r.stderr)]
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    kernels = [(n, s, c) for n, s, c in zip(names, spills, scratch) if "lkgd_gemm_resw_kernel" in n]
+    assert len(kernels) >= 30, len(kernels)
+    bad = [k for k in kernels if k[1] or k[2]]
+    assert not bad, bad
