@@ -47,7 +47,8 @@ enum {
  *
  *    A(m,k) by `mode`:
  *      LKGD_A_PLAIN     A = a0[m, k] for k < csplit else a1[m, k - csplit]        (Linear, 1x1 conv, concat input)
- *      LKGD_A_CONV3X3   k = (ky*3+kx)*Cin + c; token m = (n, y, x) on the Hout x Wout grid reads source pixel
+ *      LKGD_A_CONV3X3   k = ((ky*(Cin/64) + c/64)*3 + kx)*64 + c%64 (per kernel row and 64-channel chunk the three horizontal
+ *                       taps are consecutive K-tiles); token m = (n, y, x) on the Hout x Wout grid reads source pixel
  *                       ((y*stride+ky-1) >> ups, (x*stride+kx-1) >> ups) of the Hin x Win grid, zero outside
  *                       (pad 1); ups=1 folds nearest-2x upsampling into the gather; channel c from a0 / a1 as above
  *      LKGD_A_TCONV3    k = kt*Cin + c; token m = (b, f, s) reads frame f+kt-1 (zero outside [0,F)); Conv3d (3,1,1);

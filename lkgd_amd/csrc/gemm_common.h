@@ -4,6 +4,21 @@
 
 #define BK 64
 
+// K order of the 3x3 implicit convolution (weights packed by lkgd_amd/packing.py::pack_conv3x3):
+//   k = ((ky * (Cin/64) + c/64) * 3 + kx) * 64 + c % 64
+// i.e. for one kernel row ky and one 64-channel chunk the three horizontal taps are consecutive K-tiles.  They read the same
+// source cache lines shifted by one pixel, so the second and third hit the XCD's L2 (with tap-major order, k = tap * Cin + c,
+// a tap's lines came back Cin/64 K-tiles later, after ~10 MB of other traffic through a 4 MB L2: the A panel was fetched
+// from the fabric once per tap, profiles/r02_pmc_hbm_traffic.txt).  Every K-tile is its own gather segment.
+__device__ __forceinline__ void conv_k_decode(int k0, int Cin, int& ky, int& kx, int& c) {
+  const int t = k0 >> 6;                 // K-tile index (BK = 64)
+  const int nc = Cin >> 6;
+  const int q = t / 3;                   // ky * nc + chunk   (wave-uniform scalar divisions)
+  kx = t - q * 3;
+  ky = q / nc;
+  c = (q - ky * nc) << 6;
+}
+
 struct ARow {
   long long base;  // mode-specific row base (token index of the source image / row)
   int y, x;        // conv: top-left of the 3x3 window in the (virtual) source grid; tconv: frame index in y
@@ -22,9 +37,9 @@ __device__ __forceinline__ const half_t* a_source(const lkgd_gemm_desc& p, const
     return (const half_t*)p.a1 + r.base * p.lda1 + (k - p.csplit);
   }
   if (mode == LKGD_A_CONV3X3) {
-    int tap = k0 / p.Cin;
-    int c = k0 - tap * p.Cin + chunk * 8;
-    int ky = tap / 3, kx = tap - ky * 3;
+    int ky, kx, c;
+    conv_k_decode(k0, p.Cin, ky, kx, c);
+    c += chunk * 8;
     int vy = r.y + ky, vx = r.x + kx;
     int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
     if ((unsigned)vy >= (unsigned)Hv || (unsigned)vx >= (unsigned)Wv) return zero;
@@ -105,12 +120,12 @@ __device__ __forceinline__ void a_segment(const lkgd_gemm_desc& p, AGather<NR>& 
       g.zmask |= (r.valid ? 0u : 1u) << i;
     }
   } else if (mode == LKGD_A_CONV3X3) {
-    const int tap = k0 / p.Cin;
-    const int c = k0 - tap * p.Cin;
+    int ky, kx, c;
+    conv_k_decode(k0, p.Cin, ky, kx, c);
     const bool s1 = c >= p.csplit;
-    g.seg_k0 = tap * p.Cin + (s1 ? p.csplit : 0);
-    g.seg_end = tap * p.Cin + (s1 ? p.Cin : (p.csplit < p.Cin ? p.csplit : p.Cin));
-    const int ky = tap / 3, kx = tap - ky * 3;
+    g.seg_k0 = k0;                       // one K-tile per segment: the tap changes with every K-tile
+    g.seg_end = k0 + BK;
+    const int cs = s1 ? c - p.csplit : c;
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -119,8 +134,8 @@ __device__ __forceinline__ void a_segment(const lkgd_gemm_desc& p, AGather<NR>& 
       const bool ok = r.valid && (unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv;
       const long long rowi = r.base + (long long)(vy >> p.ups) * p.Win + (vx >> p.ups);
       const half_t* q = s1 ? (const half_t*)p.a1 + rowi * p.lda1 : (const half_t*)p.a0 + rowi * p.lda0;
-      g.ptr[i] = ok ? q + schunk * 8 : zero;
-      g.zmask |= (ok ? 0u : 1u) << i;
+      g.ptr[i] = ok ? q + cs + schunk * 8 : zero;
+      g.zmask |= 1u << i;                // pointer is final: no in-segment offset
     }
   } else if (mode == LKGD_A_TCONV3) {
     const int tap = k0 / p.Cin;
@@ -207,6 +222,7 @@ struct LeanGather {
   const half_t* aptr[NR];       // source of this thread's A rows in the current segment (chunk offset included)
   unsigned zmask;               // bit i: row i reads the zero page in this segment
   int seg_k0, seg_end;          // K range of the current segment (wave-uniform)
+  int ky, kx, cc;               // 3x3 conv: tap / first channel of the current segment (wave-uniform), stepped without divisions
 };
 
 // source pointers of the rows for the segment containing k0
@@ -227,14 +243,22 @@ __device__ __forceinline__ void lean_segment(const lkgd_gemm_desc& p, LeanGather
       st.zmask |= (ok ? 0u : 1u) << i;
     }
   } else if (MODE == LKGD_A_CONV3X3) {
-    const int tap = k0 / p.Cin;                            // wave-uniform (scalar) division
-    const int cc = k0 - tap * p.Cin;
+    // consecutive K-tiles step (kx, chunk, ky) like an odometer; only a tile's (or K slice's) first K-tile is decoded by division
+    if (k0 != 0 && k0 == st.seg_end) {
+      if (++st.kx == 3) {
+        st.kx = 0;
+        st.cc += BK;
+        if (st.cc == p.Cin) { st.cc = 0; ++st.ky; }
+      }
+    } else {
+      conv_k_decode(k0, p.Cin, st.ky, st.kx, st.cc);       // wave-uniform (scalar) divisions
+    }
+    const int ky = st.ky, kx = st.kx, cc = st.cc;
     const bool s1 = cc >= p.csplit;
-    st.seg_k0 = tap * p.Cin + (s1 ? p.csplit : 0);
-    st.seg_end = tap * p.Cin + (s1 ? p.Cin : (p.csplit < p.Cin ? p.csplit : p.Cin));
-    const int ky = tap / 3, kx = tap - ky * 3;
+    st.seg_k0 = k0;                                        // one K-tile per segment
+    st.seg_end = k0 + BK;
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-    const half_t* src = (s1 ? (const half_t*)p.a1 : (const half_t*)p.a0) + schunk * 8;
+    const half_t* src = (s1 ? (const half_t*)p.a1 + (cc - p.csplit) : (const half_t*)p.a0 + cc) + schunk * 8;
     const unsigned ld = s1 ? p.lda1 : p.lda0;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {

@@ -170,7 +170,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
   lean_rcps<MODE>(p, rcp0, rcp1);
   int st_tile = tile_begin - nc, st_kt = nk - 1, st_s = -1, st_par = 0, ep_par = 0;
   int st_k0 = 0;                // first K-tile of the staged virtual tile's slice
-  ag.seg_k0 = 0; ag.seg_end = 0; ag.zmask = 0;
+  ag.seg_k0 = 0; ag.seg_end = 0; ag.zmask = 0; ag.ky = 0; ag.kx = 0; ag.cc = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { ag.rd[i].base = -1; ag.rd[i].yx = 0; ag.aptr[i] = (const half_t*)p.zeros; }
   WideIn in;

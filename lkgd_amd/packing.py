@@ -13,9 +13,13 @@ def pack_linear(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
-    """Conv2d weight [Cout, Cin, 3, 3] -> fp16 [Cout, 9*Cin], k = (ky*3+kx)*Cin + c"""
+    """Conv2d weight [Cout, Cin, 3, 3] -> fp16 [Cout, 9*Cin], k = ((ky*(Cin/64) + c//64)*3 + kx)*64 + c%64: for one kernel
+    row and one 64-channel chunk the three horizontal taps are consecutive K-tiles (they read the same source cache lines
+    shifted by one pixel - lkgd_amd/csrc/gemm_common.h::conv_k_decode).  Cin must be a multiple of 64."""
     co, ci = w.shape[:2]
-    return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).to(torch.float16).contiguous()
+    assert ci % 64 == 0, "3x3 implicit GEMM needs Cin % 64 == 0 (conv_in uses pack_conv3x3_c8)"
+    t = w.reshape(co, ci // 64, 64, 3, 3).permute(0, 3, 1, 4, 2)      # [co, ky, chunk, kx, 64]
+    return t.reshape(co, 9 * ci).to(torch.float16).contiguous()
 
 
 def pack_conv3x3_c8(w: torch.Tensor) -> torch.Tensor:

@@ -74,10 +74,12 @@ def test_state_dict_names_match_diffusers_tree():
 def test_packing_layouts():
     from lkgd_amd import packing as pk
     g = torch.Generator().manual_seed(0)
-    w = torch.randn(6, 4, 3, 3, generator=g)
+    w = torch.randn(6, 128, 3, 3, generator=g)
     p = pk.pack_conv3x3(w)
-    assert p.shape == (6, 36) and p.dtype == torch.float16
-    assert torch.equal(p[2, (1 * 3 + 2) * 4 + 3], w[2, 3, 1, 2].half())
+    assert p.shape == (6, 9 * 128) and p.dtype == torch.float16
+    # k = ((ky * (Cin/64) + c // 64) * 3 + kx) * 64 + c % 64   (include/lkgd_hip.h section 1)
+    for (ky, kx, c) in ((1, 2, 3), (0, 0, 64), (2, 1, 127)):
+        assert torch.equal(p[2, ((ky * 2 + c // 64) * 3 + kx) * 64 + c % 64], w[2, c, ky, kx].half())
     w8 = torch.randn(5, 8, 3, 3, generator=g)
     p = pk.pack_conv3x3_c8(w8)
     assert p.shape == (5, 128) and torch.equal(p[:, 72:], torch.zeros(5, 56, dtype=torch.float16))
