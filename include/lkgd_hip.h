@@ -97,9 +97,18 @@ typedef struct lkgd_gemm_desc {
                               the CUs with 128x128 tiles; K is then cut into up to 16 slices whose fp32 partial tiles
                               go to [slice][M][N] here and a second kernel adds them in slice order and runs the
                               epilogue - deterministic, no atomics.  One GEMM at a time may use a workspace. */
+  float* colstats;         /* optional: per-(row block, column PAIR) sums of the ROUNDED outputs, fp32 [ceil(M / blk)][N / 2][2]
+                              = (sum, sum of squares) of columns 2c, 2c + 1 over the valid rows of block blk - the GroupNorm
+                              statistics (groups are even-sized) of the tensor
+                              this GEMM writes, taken while its rows pass through LDS (section 2: lkgd_groupnorm_stats_cols),
+                              so the separate statistics pass over the tensor disappears.  blk = lkgd_gemm_colstats_block(d)
+                              (256 or 32); must be NULL when that returns 0.  Deterministic (fixed-order sums, no atomics). */
 } lkgd_gemm_desc;
 
 int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream);
+/* rows per `colstats` block of the tile program lkgd_gemm_f16 will run for this descriptor (its colstats field is ignored);
+ * 0 = that program does not produce column statistics */
+int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 2. GroupNorm (32 groups) statistics + apply + SiLU on channels-last tokens.
@@ -120,6 +129,14 @@ int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, const void* x1,
                         int64_t nsamples, int64_t rows_per_sample, float* partial, float* sums, lkgd_stream_t stream);
 int lkgd_groupnorm_finalize(const float* sums, int64_t nsamples, double count_per_group, float eps, float* stats,
                             lkgd_stream_t stream);
+/* statistics of x = cat(x0[:, :c0], x1[:, :c1]) from the column sums their producing GEMMs left (lkgd_gemm_desc.colstats):
+ * cs0 / cs1 = [rows / blk][ldcs / 2][2] fp32 (column pairs) with blk0 / blk1 rows per block (rows_per_sample must be a
+ * multiple of both; channel counts and group size even);
+ * as_sums = 0 writes stats[sample][32][2] = (mean, rstd) like lkgd_groupnorm_stats, 1 writes the raw (sum, sum of squares)
+ * like lkgd_groupnorm_sums (frame-sharded path).  Replaces the read pass of F.group_norm over the tensor. */
+int lkgd_groupnorm_stats_cols(const float* cs0, int32_t blk0, int32_t ldcs0, int32_t c0, const float* cs1, int32_t blk1,
+                              int32_t ldcs1, int32_t c1, int64_t nsamples, int64_t rows_per_sample, float eps,
+                              int32_t as_sums, float* stats, lkgd_stream_t stream);
 int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
                          int64_t nsamples, int64_t rows_per_sample, const float* stats, const float* gamma,
                          const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);

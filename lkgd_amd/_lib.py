@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("s_acc", C.c_float), ("r1", C.c_float), ("r2", C.c_float),
         ("geglu", C.c_int32), ("pad_off", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("colstats", C.c_void_p),
     ]
 
 
@@ -56,6 +57,8 @@ class FsmDesc(C.Structure):
 
 SYMBOLS = {
     "lkgd_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
+    "lkgd_gemm_colstats_block": (_i32, [C.POINTER(GemmDesc)]),
+    "lkgd_groupnorm_stats_cols": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _vp, _vp]),
     "lkgd_groupnorm_chunks": (_i32, [_i64, _i32]),
     "lkgd_groupnorm_stats": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp]),
     "lkgd_groupnorm_sums": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp]),

@@ -323,6 +323,7 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
 extern "C" int lkgd_gemm_resw_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_resw.hip
 extern "C" int lkgd_gemm_resw_ok(const lkgd_gemm_desc* d, int cus);
+extern "C" int lkgd_gemm_resw_colstats_ok(const lkgd_gemm_desc* d);
 
 // tuning/testing knob (not part of the reference-facing ABI): 0 = auto, 1 = force 128x128, 2 = force 256x128 ring,
 // 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320),
@@ -369,29 +370,24 @@ static int wide_split(const lkgd_gemm_desc* d, long long tiles_wide, int cus) {
 
 extern "C" void lkgd_debug_set_gemm_splitk(int on) { gemm_splitk_enabled = on != 0; }
 
-extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
-  int rc = check_desc(d);
-  if (rc != LKGD_OK) return rc;
-  LKGD_DEVICE_ONCE_BEGIN
-    if (hipFuncSetAttribute((const void*)lkgd_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)lkgd_gemm_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GEMM2_LDS) != hipSuccess)
-      return LKGD_E_LAUNCH;
-  LKGD_DEVICE_ONCE_END
+static int gemm_cus(int* cus_out) {
   static std::atomic<int> cus_of[64];
-  int cus = 0;
-  {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return LKGD_E_LAUNCH;
-    cus = cus_of[dev].load(std::memory_order_relaxed);
-    if (!cus) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LKGD_E_LAUNCH;
-      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      cus_of[dev].store(cus, std::memory_order_relaxed);
-    }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return LKGD_E_LAUNCH;
+  int cus = cus_of[dev].load(std::memory_order_relaxed);
+  if (!cus) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LKGD_E_LAUNCH;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cus_of[dev].store(cus, std::memory_order_relaxed);
   }
+  *cus_out = cus;
+  return LKGD_OK;
+}
+
+// tile-program choice for a checked descriptor: 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide (256x320), 5 = row-panel,
+// 6 = resident-weight; *wide_ks_out = K slices of the 256x320 program (1 = none); negative = LKGD_E_*
+static int gemm_pick(const lkgd_gemm_desc* d, int cus, int* wide_ks_out) {
   // GEGLU weights are packed for one tile family (interleave width 80 -> 256x320 tiles, 32 -> 128-wide tiles)
   // the persistent kernels move epilogue rows as 16-byte chunks: 8-channel granularity and 16-byte aligned rows
   const bool rows16 = d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->out) &&
@@ -458,11 +454,53 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   if (pick == 4 && !wide_ok) pick = 3;
   if (pick == 3 && (!stream_ok || d->M <= 256)) pick = (d->K >= 960 && d->M > 256) ? 2 : 1;
   if (d->geglu == 80 && pick != 4 && pick != 6) return LKGD_E_SHAPE;   // 80-wide interleave: 256x320 / resident-weight kernels
+  *wide_ks_out = wide_ks;
+  return pick;
+}
+
+// wide_split() for a forced 256x320 variant follows the same slicing rule as the automatic one
+static int gemm_wide_slices(const lkgd_gemm_desc* d, int cus, int pick, int wide_ks) {
+  if (pick != 4) return 1;
+  if (gemm_variant_override == 4) {
+    const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
+    wide_ks = wide_split(d, tiles_wide, cus);
+  }
+  return wide_ks >= 2 ? wide_ks : 1;
+}
+
+extern "C" int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d) {
+  if (!d || check_desc(d) != LKGD_OK || d->geglu || d->N % 8) return 0;
+  int cus = 0;
+  if (gemm_cus(&cus) != LKGD_OK) return 0;
+  int wide_ks = 1;
+  const int pick = gemm_pick(d, cus, &wide_ks);
+  if (pick == 6) return lkgd_gemm_resw_colstats_ok(d) ? 32 : 0;
+  // the 256x320 program sums the columns of the row segments it parks in LDS: whole 320-column tiles, unsliced K
+  if (pick == 4 && gemm_wide_slices(d, cus, pick, wide_ks) == 1 && d->N % 320 == 0 && d->ldc % 8 == 0 && aligned16(d->out))
+    return 256;
+  return 0;
+}
+
+extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc != LKGD_OK) return rc;
+  LKGD_DEVICE_ONCE_BEGIN
+    if (hipFuncSetAttribute((const void*)lkgd_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)lkgd_gemm_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GEMM2_LDS) != hipSuccess)
+      return LKGD_E_LAUNCH;
+  LKGD_DEVICE_ONCE_END
+  int cus = 0;
+  if ((rc = gemm_cus(&cus)) != LKGD_OK) return rc;
+  int wide_ks = 1;
+  const int pick = gemm_pick(d, cus, &wide_ks);
+  if (pick < 0) return pick;
+  if (d->colstats && lkgd_gemm_colstats_block(d) == 0) return LKGD_E_SHAPE;   // the chosen program produces no column sums
   if (pick == 6) return lkgd_gemm_resw_launch(d, (hipStream_t)stream, cus);
   if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
   if (pick == 4) {
-    if (v == 4) wide_ks = wide_split(d, tiles_wide, cus);      // forced variant: same slicing rule
-    const int ks = wide_ks >= 2 ? wide_ks : 1;
+    const int ks = gemm_wide_slices(d, cus, pick, wide_ks);
     rc = lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus, ks);
     if (rc != LKGD_OK || ks == 1) return rc;
     const int tn128 = (d->N + BN - 1) / BN;

@@ -147,8 +147,9 @@ __device__ __forceinline__ void resw_wait(ReswPiece& c) {
   if (SRC & 4) resw_tie5(c.r2);
 }
 
-// SRC: bit 0 = row-indexed bias, bit 1 = res1, bit 2 = res2 present (plain epilogue only)
-template <int NK, bool GEGLU, int SRC>
+// SRC: bit 0 = row-indexed bias, bit 1 = res1, bit 2 = res2 present (plain epilogue only); CS: column statistics
+// (lkgd_gemm_desc.colstats) are compiled in - only for the source sets that keep the register budget (resw_has_cs)
+template <int NK, bool GEGLU, int SRC, bool CS>
 __global__ __launch_bounds__(RW_NT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_resw_kernel(const lkgd_gemm_desc p, int nslab, int per) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = NK * 2;                  // K-steps of 32
@@ -305,12 +306,39 @@ __global__ __launch_bounds__(RW_NT, 2) __attribute__((amdgpu_num_vgpr(96))) void
           resw_store16(outp + (unsigned long long)(unsigned)mr * (unsigned)p.ldc + slab * RW_SLAB + cc * 8, v[kk], mr, p.M);
         }
       };
+      // column statistics of the block's rounded outputs (lkgd_gemm_desc.colstats, 32-row blocks): lanes 0-39 add four
+      // channels each over the 16 row segments of a fragment while it sits in the patch
+      const bool cs_on = CS && p.colstats != nullptr;
+      float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};      // this lane's two channel PAIRS
+      auto colsum = [&](int j) {
+        if (CS && cs_on && lane < 40) {
+          const int left = p.M - (blk * 32 + j * 16);
+          const int nrows = left >= 16 ? 16 : (left > 0 ? left : 0);
+          #pragma unroll
+          for (int r0 = 0; r0 < 16; r0 += 8) {      // eight rows in flight at a time (16 registers)
+            half4_t u[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) u[r] = *(const half4_t*)(scr + (r0 + r) * RW_PITCH + lane * 8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const half_t one = r0 + r < nrows ? (half_t)1.0f : (half_t)0.0f;
+              const half2_t w2 = {one, one};
+              const half2_t p0 = {u[r][0], u[r][1]}, p1 = {u[r][2], u[r][3]};
+              csum[0] = __builtin_amdgcn_fdot2(p0, w2, csum[0], false);
+              csum[1] = __builtin_amdgcn_fdot2(p1, w2, csum[1], false);
+              csq[0] = __builtin_amdgcn_fdot2(p0, p0 * w2, csq[0], false);
+              csq[1] = __builtin_amdgcn_fdot2(p1, p1 * w2, csq[1], false);
+            }
+          }
+        }
+      };
       // two pieces in flight; every wait names the operations younger than the piece it needs (loads issued after it, stores)
       if (NSRC) { issue(pc0, 0, ReswIC<0>{}); issue(pc1, 0, ReswIC<1>{}); resw_wait<PL, SRC>(pc0); }
       compute(pc0, ReswIC<0>{}, ReswIC<0>{});
       if (NSRC) { issue(pc0, 1, ReswIC<0>{}); resw_wait<PL, SRC>(pc1); }
       compute(pc1, ReswIC<0>{}, ReswIC<1>{});
       if (NSRC) issue(pc1, 1, ReswIC<1>{});
+      colsum(0);
 #ifdef RESW_X_STAMPS
       unsigned long long qa, qb;
       RSTAMP(qa)
@@ -325,7 +353,11 @@ __global__ __launch_bounds__(RW_NT, 2) __attribute__((amdgpu_num_vgpr(96))) void
       if (NSRC) resw_wait<5, SRC>(pc1);
       compute(pc1, ReswIC<1>{}, ReswIC<1>{});
       RSTAMP(q2)
+      colsum(1);
       rows(1);
+      if (CS && cs_on && lane < 40)
+        *(float4_t*)(p.colstats + ((long long)blk * (p.N / 2) + slab * (RW_SLAB / 2) + 2 * lane) * 2) =
+            (float4_t){csum[0], csq[0], csum[1], csq[1]};
     } else {
       // slab rows [0,80) = hidden, [80,160) = gate of output columns slab*80 + [0,80)
       auto epi = [&](auto jc) {
@@ -387,21 +419,30 @@ __global__ __launch_bounds__(RW_NT, 2) __attribute__((amdgpu_num_vgpr(96))) void
 // slow here: the residual loads are issued and awaited by hand, and spill code placed between a load and its wait would
 // save a register whose data has not arrived yet.
 static constexpr bool resw_has(int nk, int src) { return nk >= 4 ? src <= 5 : (src == 0 || src == 1 || src == 2 || src == 4 || src == 6); }
+static constexpr bool resw_has_cs(int nk, int src) { return src == 0 || src == 2; }      // bare / bias, + one residual (proj_out)
 
 template <int NK>
 static void resw_launch_nk(const lkgd_gemm_desc* d, hipStream_t stream, int grid, int lds, int nslab, int per, bool attr_only) {
   const int src = (d->rowbias ? 1 : 0) | (d->res1 ? 2 : 0) | (d->res2 ? 4 : 0);
-#define RW_ONE(G, S)                                                                                                    \
-  if constexpr (G || resw_has(NK, S)) {                                                                                 \
+  const bool cs = d->colstats != nullptr;
+#define RW_ONE(G, S, C)                                                                                                 \
+  if constexpr (G || (C ? resw_has_cs(NK, S) : resw_has(NK, S))) {                                                      \
     if (attr_only)                                                                                                      \
-      (void)hipFuncSetAttribute((const void*)lkgd_gemm_resw_kernel<NK, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-    else if (G ? d->geglu != 0 : (d->geglu == 0 && src == S))                                                           \
-      hipLaunchKernelGGL((lkgd_gemm_resw_kernel<NK, G, S>), dim3(grid), dim3(RW_NT), lds, stream, *d, nslab, per);      \
+      (void)hipFuncSetAttribute((const void*)lkgd_gemm_resw_kernel<NK, G, S, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    else if (G ? d->geglu != 0 : (d->geglu == 0 && src == S && cs == C))                                                \
+      hipLaunchKernelGGL((lkgd_gemm_resw_kernel<NK, G, S, C>), dim3(grid), dim3(RW_NT), lds, stream, *d, nslab, per);   \
   }
-  RW_ONE(true, 0)
-  RW_ONE(false, 0) RW_ONE(false, 1) RW_ONE(false, 2) RW_ONE(false, 3)
-  RW_ONE(false, 4) RW_ONE(false, 5) RW_ONE(false, 6) RW_ONE(false, 7)
+  RW_ONE(true, 0, false)
+  RW_ONE(false, 0, false) RW_ONE(false, 1, false) RW_ONE(false, 2, false) RW_ONE(false, 3, false)
+  RW_ONE(false, 4, false) RW_ONE(false, 5, false) RW_ONE(false, 6, false) RW_ONE(false, 7, false)
+  RW_ONE(false, 0, true) RW_ONE(false, 2, true)
 #undef RW_ONE
+}
+
+// may a launch of this descriptor on the resident-weight kernel carry column statistics?
+extern "C" int lkgd_gemm_resw_colstats_ok(const lkgd_gemm_desc* d) {
+  const int src = (d->rowbias ? 1 : 0) | (d->res1 ? 2 : 0) | (d->res2 ? 4 : 0);
+  return !d->geglu && resw_has_cs(d->K / 64, src);
 }
 
 // does the resident-weight kernel cover this problem on a device with `cus` compute units?  (lkgd_gemm_f16's dispatch)
@@ -423,6 +464,7 @@ extern "C" int lkgd_gemm_resw_ok(const lkgd_gemm_desc* d, int cus) {
 // grid = 8 XCD classes x (per x nslab) workgroups: every XCD runs all nslab slabs over its eighth of the rows
 extern "C" int lkgd_gemm_resw_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus) {
   if (!lkgd_gemm_resw_ok(d, cus)) return LKGD_E_SHAPE;
+  if (d->colstats && !lkgd_gemm_resw_colstats_ok(d)) return LKGD_E_SHAPE;
   const int nk = d->K / 64;
   const int nslab = d->N / RW_SLAB;
   const int per = (cus / 8) / nslab;

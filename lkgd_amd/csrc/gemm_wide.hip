@@ -331,6 +331,12 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
       constexpr bool lds_out = LDSOUT && !SPLIT;        // the launcher checks N % 320 == 0, ldc % 8 == 0, 16-byte aligned out
       char* scr = smem + (cur ^ 1) * WSTAGE_BYTES + w * (16 * WIDE_OUT_PITCH);
       if (lds_out) __builtin_amdgcn_s_barrier();
+      // Column statistics (lkgd_gemm_desc.colstats: the GroupNorm sums of the tensor this GEMM writes).  A token fragment
+      // sits in LDS as 16 row segments of the wave's 160 channels before it is stored: lanes 0-39 add up four channels each
+      // over the rows (the ROUNDED fp16 values the consumer will read), carry the sums over the tile's four fragments, and
+      // the four waves of a channel half are combined in a fixed order at the end of the epilogue - no atomics.
+      const bool cs_on = lds_out && p.colstats != nullptr;
+      float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};      // this lane's two channel PAIRS (GroupNorm groups are even-sized)
       // accumulator fragments are read where they are used (one or two live at a time, not all ten of a token fragment)
       auto epi = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -408,6 +414,28 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
           // the fragment's rows as 16-byte pieces: piece c of the wave's 16 x (20 | 10) grid -> row c / per, column piece c % per
           const int per = gg ? 10 : 20;                               // 16-byte pieces per row (80 | 160 channels)
           const long long mrow0 = (long long)tm * WBM + wr * 64 + j * 16;
+          if (cs_on && lane_e < 40) {
+            // branch-free over the 16 rows (rows past M are weighted 0): the reads issue back to back; per channel PAIR
+            // one v_dot2_f32_f16 for the sum and one for the sum of squares (fp16 products are exact in fp32)
+            const long long left = (long long)p.M - mrow0;
+            const int nrows = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+            #pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {      // eight rows in flight at a time (16 registers)
+              half4_t u[8];
+#pragma unroll
+              for (int r = 0; r < 8; ++r) u[r] = *(const half4_t*)(scr + (r0 + r) * WIDE_OUT_PITCH + lane_e * 8);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const half_t one = r0 + r < nrows ? (half_t)1.0f : (half_t)0.0f;
+                const half2_t w2 = {one, one};
+                const half2_t p0 = {u[r][0], u[r][1]}, p1 = {u[r][2], u[r][3]};
+                csum[0] = __builtin_amdgcn_fdot2(p0, w2, csum[0], false);
+                csum[1] = __builtin_amdgcn_fdot2(p1, w2, csum[1], false);
+                csq[0] = __builtin_amdgcn_fdot2(p0, p0 * w2, csq[0], false);
+                csq[1] = __builtin_amdgcn_fdot2(p1, p1 * w2, csq[1], false);
+              }
+            }
+          }
           const int ncol0 = gg ? tn * 160 + wc * 80 : tn * WBN + wc * 160;
 #pragma unroll
           for (int kk = 0; kk < 5; ++kk) {
@@ -429,6 +457,21 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
   }
       WIDE_EPI(0) WIDE_EPI(1) WIDE_EPI(2) WIDE_EPI(3)
 #undef WIDE_EPI
+      if (cs_on) {
+        // [row group wr][160 channel pairs][sum, sum of squares] behind the eight waves' row patches in the free stage; the
+        // next K-tile body starts with a barrier before anything is loaded into this stage
+        float* part = (float*)(smem + (cur ^ 1) * WSTAGE_BYTES + 8 * 16 * WIDE_OUT_PITCH);
+        if (lane_e < 40)
+          *(float4_t*)(part + (wr * (WBN / 2) + wc * 80 + 2 * lane_e) * 2) = (float4_t){csum[0], csq[0], csum[1], csq[1]};
+        __builtin_amdgcn_s_barrier();
+        if (t < WBN / 2) {
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { a += part[(g * (WBN / 2) + t) * 2]; b += part[(g * (WBN / 2) + t) * 2 + 1]; }
+          typedef float float2v __attribute__((ext_vector_type(2)));
+          *(float2v*)(p.colstats + ((long long)tm * (p.N / 2) + tn * (WBN / 2) + t) * 2) = (float2v){a, b};
+        }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's trailing loads must land before the LDS is released
@@ -449,8 +492,9 @@ extern "C" void lkgd_debug_set_wide_lds_out(int on) { wide_lds_out_override = on
 
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
   LKGD_DEVICE_ONCE_BEGIN
-    const void* fns[7] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, false>,
+    const void* fns[9] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, false>,
                           (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>,
+                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, true>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, true>,
                           (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>,
                           (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>};
     for (const void* f : fns)
@@ -464,8 +508,10 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
   if (d->M >= (1 << 24)) return LKGD_E_SHAPE;            // float-reciprocal row decomposition (gemm_common.h)
   float* ws = (float*)d->workspace;
   // plain linears without GEGLU, whole 320-column tiles, 16-byte aligned output rows: the rows leave through LDS (see the epilogue)
-  const bool lds_out = wide_lds_out_override != 0 && ksplit == 1 && d->mode == LKGD_A_PLAIN && !d->geglu && d->N % WBN == 0 &&
-                       d->ldc % 8 == 0 && aligned16(d->out);
+  // (the convolutions only when column statistics are asked for: they are summed from the rows in LDS)
+  const bool lds_ok = ksplit == 1 && !d->geglu && d->N % WBN == 0 && d->ldc % 8 == 0 && aligned16(d->out);
+  if (d->colstats && !lds_ok) return LKGD_E_SHAPE;
+  const bool lds_out = lds_ok && (d->colstats ? true : (wide_lds_out_override != 0 && d->mode == LKGD_A_PLAIN));
 #define WIDE_LAUNCH(MODE_)                                                                                              \
   {                                                                                                                     \
     if (ksplit > 1)                                                                                                     \
@@ -473,8 +519,12 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
     else                                                                                                                \
       hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, false>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n); \
   }
-  if (lds_out)
+  if (lds_out && d->mode == LKGD_A_PLAIN)
     hipLaunchKernelGGL((lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+  else if (lds_out && d->mode == LKGD_A_CONV3X3)
+    hipLaunchKernelGGL((lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
+  else if (lds_out && d->mode == LKGD_A_TCONV3)
+    hipLaunchKernelGGL((lkgd_gemm_wide_kernel<LKGD_A_TCONV3, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
   else
   if (d->mode == LKGD_A_PLAIN) WIDE_LAUNCH(LKGD_A_PLAIN)
   else if (d->mode == LKGD_A_CONV3X3) WIDE_LAUNCH(LKGD_A_CONV3X3)

@@ -115,6 +115,61 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, 
   }
 }
 
+// Statistics from the column sums the producing GEMMs left (lkgd_gemm_desc.colstats): one workgroup per (sample, group)
+// walks the group's channels x the sample's row blocks in a fixed thread -> element map and reduces in a fixed tree
+// (bitwise reproducible; fp64 across blocks).  A group may straddle the two sources of a concatenated input.
+__global__ __launch_bounds__(256) void gn_cols_kernel(const float* cs0, int blk0, int ld0, int c0, const float* cs1, int blk1,
+                                                      int ld1, int c1, long long rows_per_sample, double inv_count, float eps,
+                                                      int as_sums, float* stats) {
+  __shared__ double sa[256], sb[256];
+  const int t = threadIdx.x;
+  const int g = blockIdx.x;
+  const long long sample = blockIdx.y;
+  const int gs = (c0 + c1) / GN_GROUPS;
+  double a = 0.0, b = 0.0;
+  for (int src = 0; src < 2; ++src) {
+    const float* cs = src ? cs1 : cs0;
+    if (!cs) continue;
+    const int blk = src ? blk1 : blk0, ld = src ? ld1 : ld0;
+    // this group's channels inside the source: [lo, hi) in the source's own channel numbering
+    int lo = g * gs - (src ? c0 : 0), hi = lo + gs;
+    const int cmax = src ? c1 : c0;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > cmax ? cmax : hi;
+    const int nch = hi - lo;
+    if (nch <= 0) continue;
+    // the column sums are kept per channel PAIR (2c, 2c + 1): groups and sources are even-sized
+    const int plo = lo >> 1, npair = nch >> 1;
+    const long long nb = rows_per_sample / blk, b0 = sample * nb;
+    const long long total = nb * npair;
+    for (long long e = t; e < total; e += 256) {
+      const long long bi = e / npair;
+      const int c = plo + (int)(e - bi * npair);
+      const float* q = cs + ((b0 + bi) * (ld >> 1) + c) * 2;
+      a += q[0]; b += q[1];
+    }
+  }
+  sa[t] = a; sb[t] = b;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { sa[t] += sa[t + o]; sb[t] += sb[t + o]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    float* o = stats + (sample * GN_GROUPS + g) * 2;
+    if (as_sums) {
+      o[0] = (float)sa[0]; o[1] = (float)sb[0];
+    } else {
+      const double mean = sa[0] * inv_count;
+      double var = sb[0] * inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      o[0] = (float)mean;
+      o[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+}
+
 // frame-sharded path: chunk partials -> raw fp32 sums per (sample, group); finalise from (all-reduced) sums
 __global__ __launch_bounds__(256) void gn_sums_kernel(const float* partial, int nchunks, float* sums) {
   const int lane = threadIdx.x & 63;
@@ -216,6 +271,22 @@ extern "C" int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, con
   double inv = 1.0 / ((double)rows_per_sample * (double)((c0 + c1) / GN_GROUPS));
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
                      nchunks, inv, eps, stats);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+extern "C" int lkgd_groupnorm_stats_cols(const float* cs0, int32_t blk0, int32_t ldcs0, int32_t c0, const float* cs1,
+                                         int32_t blk1, int32_t ldcs1, int32_t c1, int64_t nsamples, int64_t rows_per_sample,
+                                         float eps, int32_t as_sums, float* stats, lkgd_stream_t stream) {
+  if (!cs0 || !stats || (c1 > 0 && !cs1)) return LKGD_E_NULL;
+  const int C = c0 + c1;
+  if ((C / GN_GROUPS) % 2 || c0 % 2 || c1 % 2 || ldcs0 % 2 || ldcs1 % 2) return LKGD_E_SHAPE;      // pair granularity
+  if (c0 <= 0 || c1 < 0 || C % GN_GROUPS || blk0 <= 0 || ldcs0 < c0 || (c1 > 0 && (blk1 <= 0 || ldcs1 < c1))) return LKGD_E_SHAPE;
+  if (nsamples <= 0 || nsamples > 65535 || rows_per_sample <= 0 || rows_per_sample % blk0 || (c1 > 0 && rows_per_sample % blk1))
+    return LKGD_E_SHAPE;
+  const double inv = 1.0 / ((double)rows_per_sample * (double)(C / GN_GROUPS));
+  hipLaunchKernelGGL(gn_cols_kernel, dim3(GN_GROUPS, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, cs0, blk0, ldcs0,
+                     c0, c1 > 0 ? cs1 : (const float*)nullptr, blk1, ldcs1, c1, (long long)rows_per_sample, inv, eps, as_sums,
+                     stats);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 

@@ -4,6 +4,7 @@ a CUDA(HIP) tensor of the expected dtype - there is no CPU path."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -90,9 +91,13 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
          mode: int = A_PLAIN, Cin: int = 0, conv: Optional[Tuple[int, int, int, int, int, int]] = None,
          tconv: Optional[Tuple[int, int]] = None, rowbias: Optional[torch.Tensor] = None,
          rowmap: Optional[RowMap] = None, res1: Optional[torch.Tensor] = None, r1: float = 1.0,
-         res2: Optional[torch.Tensor] = None, r2: float = 1.0, s_acc: float = 1.0, geglu: int = 0) -> torch.Tensor:
+         res2: Optional[torch.Tensor] = None, r2: float = 1.0, s_acc: float = 1.0, geglu: int = 0,
+         colstats: int = 0) -> torch.Tensor:
     """out = epilogue(A(.) @ w.T) - see include/lkgd_hip.h section 1.  ``conv`` = (Hout, Wout, Hin, Win, stride, ups);
-    ``tconv`` = (F, HW)."""
+    ``tconv`` = (F, HW).  ``colstats`` = rows per GroupNorm sample (0 = off): ``out`` feeds a GroupNorm next - where the
+    tile program that will run supports it and its row blocks tile the samples, the GEMM leaves the per-(row block, channel
+    pair) sums of its rounded outputs and ``out`` carries them (``out._lkgd_colstats``) to :func:`groupnorm_stats`, which
+    then skips its read pass over the tensor."""
     _req(a0, torch.float16, "a0"); _req(w, torch.float16, "w"); _req(out, torch.float16, "out")
     d = GemmDesc()
     d.a0, d.w, d.out = a0.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -130,6 +135,12 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     if M < 12288:               # few-row problems may cut K into slices (lkgd_hip.h: lkgd_gemm_desc.workspace)
         ws = splitk_workspace(out.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if colstats and COLSTATS and out.shape[0] == M and out.shape[1] == N:
+        blk = _L().lkgd_gemm_colstats_block(C.byref(d))
+        if blk > 0 and int(colstats) % blk == 0:
+            buf = torch.empty((M + blk - 1) // blk, N // 2, 2, dtype=torch.float32, device=out.device)   # channel pairs
+            d.colstats = buf.data_ptr()
+            out._lkgd_colstats = (buf, blk)
     ev = GEMM_EVENTS
     if ev is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -142,9 +153,40 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     return out
 
 
+#: A/B switch of the GroupNorm statistics from the producing GEMM's epilogue (False = always the separate read pass)
+COLSTATS = os.environ.get("LKGD_NO_COLSTATS", "0") != "1"
+
+
+def _stats_from_cols(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, rows_per_sample: int, eps: float,
+                     as_sums: bool) -> Optional[torch.Tensor]:
+    """(mean, rstd) - or raw sums - from the column sums the tensors' producing GEMMs attached (ops.gemm(colstats=True));
+    None when a tensor carries none or its row blocks do not tile the samples"""
+    if not COLSTATS:
+        return None
+    cs0 = getattr(x0, "_lkgd_colstats", None)
+    cs1 = getattr(x1, "_lkgd_colstats", None) if x1 is not None else None
+    if cs0 is None or (x1 is not None and cs1 is None):
+        return None
+    (b0, k0), (b1, k1) = cs0, (cs1 if cs1 is not None else (None, 1))
+    if (rows_per_sample % k0 or rows_per_sample % k1 or 2 * b0.shape[1] != x0.shape[1] or
+            (b1 is not None and 2 * b1.shape[1] != x1.shape[1]) or ((x0.shape[1] + (x1.shape[1] if x1 is not None else 0)) // 32) % 2):
+        return None
+    if b0.shape[0] * k0 < nsamples * rows_per_sample or (b1 is not None and b1.shape[0] * k1 < nsamples * rows_per_sample):
+        return None
+    out = torch.empty(nsamples, 32, 2, dtype=torch.float32, device=x0.device)
+    check(_L().lkgd_groupnorm_stats_cols(b0.data_ptr(), k0, 2 * b0.shape[1], x0.shape[1], _ptr(b1), k1,
+                                         2 * b1.shape[1] if b1 is not None else 0, x1.shape[1] if x1 is not None else 0,
+                                         nsamples, rows_per_sample, eps, 1 if as_sums else 0, out.data_ptr(), _stream()),
+          "lkgd_groupnorm_stats_cols")
+    return out
+
+
 def groupnorm_stats(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, rows_per_sample: int,
                     eps: float) -> torch.Tensor:
     _req(x0, torch.float16, "x0")
+    st = _stats_from_cols(x0, x1, nsamples, rows_per_sample, eps, False)
+    if st is not None:
+        return st
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
     L = _L()
@@ -160,6 +202,9 @@ def groupnorm_stats(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int,
 def groupnorm_sums(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, rows_per_sample: int) -> torch.Tensor:
     """raw fp32 (sum, sumsq) per (sample, group) of the local rows (frame-sharded GroupNorm)"""
     _req(x0, torch.float16, "x0")
+    st = _stats_from_cols(x0, x1, nsamples, rows_per_sample, 0.0, True)
+    if st is not None:
+        return st
     c0 = x0.shape[1]
     c1 = x1.shape[1] if x1 is not None else 0
     L = _L()

@@ -48,7 +48,7 @@ class _RecordingLib:
 
         def call(*args):
             rc = fn(*args)
-            if name == "lkgd_groupnorm_chunks":       # pure host helper, returns a count
+            if name in ("lkgd_groupnorm_chunks", "lkgd_gemm_colstats_block"):     # pure host helpers, return a count
                 return rc
             flop = None
             if name == "lkgd_gemm_f16":

@@ -658,7 +658,7 @@ class TransformerSpatioTemporalModel(nn.Module):
             h_s = blk.run(ctx, h)
             h = tblk.run(ctx, h_s, posemb, self._alpha, order)
         out = ctx.new(T, Cc)
-        ops.gemm(h, pk.wout, out, M=T, N=Cc, K=Cc, bias=pk.bout, res1=x)
+        ops.gemm(h, pk.wout, out, M=T, N=Cc, K=Cc, bias=pk.bout, res1=x, colstats=ctx.HW)   # -> the next resnet's norm1
         return out
 
 
@@ -739,12 +739,12 @@ class SpatioTemporalResBlock(nn.Module):
         tgeo = (ctx.F + 2, ctx.HW, ctx.F, 1) if ctx.frames_sharded else (ctx.F, ctx.HW, ctx.F, 0)
         h = ctx.new(T, Cout)
         ops.gemm(n3, pk.tw1, h, M=T, N=Cout, K=3 * Cout, bias=pk.tb1, mode=ops.A_TCONV3, Cin=Cout,
-                 tconv=tgeo, rowbias=ctx.temb_all[:, pk.toff_t:pk.toff_t + Cout], rowmap=bmap)
+                 tconv=tgeo, rowbias=ctx.temb_all[:, pk.toff_t:pk.toff_t + Cout], rowmap=bmap, colstats=ctx.F * ctx.HW)   # -> tn2
         n4 = self._temporal_norm(ctx, h, pk.tn2, pk.teps)
         out = ctx.new(T, Cout)
         # temporal = s + conv2(..); AlphaBlender: alpha*s + (1-alpha)*temporal = s + (1-alpha)*conv2(..)
         ops.gemm(n4, pk.tw2, out, M=T, N=Cout, K=3 * Cout, bias=pk.tb2, mode=ops.A_TCONV3, Cin=Cout,
-                 tconv=tgeo, s_acc=1.0 - pk.alpha, res1=s)
+                 tconv=tgeo, s_acc=1.0 - pk.alpha, res1=s, colstats=ctx.HW)    # -> the next block's (spatial) GroupNorm
         return out
 
     @staticmethod

@@ -24,6 +24,22 @@ def _free_port():
     return p
 
 
+def _collect(procs, q, world, timeout=600):
+    """one result per rank; a rank that dies (exception in the worker) fails the test at once instead of letting the
+    parent sit in q.get until the timeout"""
+    import queue
+    import time
+    results, t0 = [], time.time()
+    while len(results) < world:
+        try:
+            results.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"worker process exited with {dead}"
+            assert time.time() - t0 < timeout, "timed out waiting for the ranks"
+    return results
+
+
 def _inputs(frames, guidance_on):
     g = torch.Generator().manual_seed(77)
     lat0 = torch.randn(1, frames, 4, 8, 8, generator=g)
@@ -126,7 +142,7 @@ def test_sharded_controlnet_lk_loop_equals_single_process(world, frames):
     procs = [ctx.Process(target=_worker_cn, args=(r, world, port, frames, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in range(world)]
+    results = _collect(procs, q, world)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -176,7 +192,7 @@ def test_sharded_dit_loop_equals_single_process(world):
     procs = [ctx.Process(target=_worker_dit, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in range(world)]
+    results = _collect(procs, q, world)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -195,7 +211,7 @@ def test_sharded_loop_equals_single_process(world, frames, guidance_on):
     procs = [ctx.Process(target=_worker, args=(r, world, port, frames, guidance_on, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in range(world)]
+    results = _collect(procs, q, world)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

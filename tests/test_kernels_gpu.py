@@ -727,3 +727,88 @@ def test_gemm_resident_weight_kernel():
             assert torch.equal(out, out4), f"resw geglu vs 256x320 {M}x{C}"
     finally:
         L.lkgd_debug_set_gemm_variant(0)
+
+
+def test_groupnorm_statistics_from_gemm_epilogues():
+    """lkgd_gemm_desc.colstats: the producing GEMM leaves per-(row block, channel) sums of its rounded outputs; the
+    GroupNorm statistics taken from them equal the statistics of the separate read pass over the same fp16 tensor
+    (same values, another summation order) - 3x3 conv, temporal conv and a plain linear on the 256x320 program (256-row
+    blocks, ragged last tile), the resident-weight program (32-row blocks), a two-source input whose groups straddle the
+    sources, the 5-D temporal form and the raw-sums form of the frame-sharded path"""
+    from lkgd_amd import _lib, ops
+    from lkgd_amd.packing import pack_conv3x3, pack_tconv3
+    g = torch.Generator().manual_seed(909)
+    Nimg, H, W = 4, 16, 32                       # 512 tokens per image: two 256-row tiles
+    T = Nimg * H * W
+
+    def stats_ref(x, nsamples, rows):
+        xs = x.float().reshape(nsamples, rows, 32, -1)
+        m = xs.mean(dim=(1, 3))
+        v = xs.var(dim=(1, 3), unbiased=False)
+        return torch.stack([m, 1.0 / torch.sqrt(v + 1e-5)], dim=-1)
+
+    def check(out, x1=None, nsamples=Nimg, rows=H * W):
+        assert getattr(out, "_lkgd_colstats", None) is not None, "the GEMM did not attach column sums"
+        got = ops.groupnorm_stats(out, x1, nsamples, rows, 1e-5)
+        ops.COLSTATS = False
+        try:
+            two_pass = ops.groupnorm_stats(out, x1, nsamples, rows, 1e-5)
+        finally:
+            ops.COLSTATS = True
+        full = out if x1 is None else torch.cat([out, x1], dim=1)
+        ref = stats_ref(full.cpu(), nsamples, rows)
+        assert torch.allclose(got.cpu(), two_pass.cpu(), rtol=2e-5, atol=2e-6)
+        assert torch.allclose(got.cpu(), ref, rtol=1e-3, atol=1e-4)
+        sums = ops.groupnorm_sums(out, x1, nsamples, rows)
+        cnt = rows * full.shape[1] // 32
+        assert torch.allclose(sums.cpu()[..., 0] / cnt, ref[..., 0], rtol=1e-3, atol=1e-4)
+
+    # (small shapes: the 256x320 program is forced - the automatic dispatch would give 16 tiles to the 128x128 program,
+    # which attaches nothing, as the last case checks)
+    _lib.lib().lkgd_debug_set_gemm_variant(4)
+    # 3x3 conv 320 -> 640 with time-embedding row bias (ResnetBlock conv1 -> norm2)
+    x = _h(torch.randn(T, 320, generator=g)).to(DEV)
+    w = torch.randn(640, 320, 3, 3, generator=g) / (9 * 320) ** 0.5
+    temb = _h(torch.randn(Nimg, 640, generator=g)).to(DEV)
+    out = torch.empty(T, 640, dtype=torch.float16, device=DEV)
+    ops.gemm(x, pack_conv3x3(w).to(DEV), out, M=T, N=640, K=9 * 320, bias=torch.randn(640, generator=g).to(DEV),
+             mode=ops.A_CONV3X3, Cin=320, conv=(H, W, H, W, 1, 0), rowbias=temb, rowmap=ops.rowmap_div(H * W), colstats=H * W)
+    check(out)
+    # a second tensor (320 channels) as the other source of a concatenated input: 960 channels, 30 per group
+    out2 = torch.empty(T, 320, dtype=torch.float16, device=DEV)
+    w2 = torch.randn(320, 320, 3, 3, generator=g) / (9 * 320) ** 0.5
+    ops.gemm(x, pack_conv3x3(w2).to(DEV), out2, M=T, N=320, K=9 * 320, mode=ops.A_CONV3X3, Cin=320, conv=(H, W, H, W, 1, 0),
+             res1=x, colstats=H * W)
+    check(out, out2)
+    # temporal conv over F = 4 frames, statistics across the frames of a clip (5-D GroupNorm: one sample = F * HW rows)
+    wt = torch.randn(320, 320, 3, 1, 1, generator=g) / (3 * 320) ** 0.5
+    out3 = torch.empty(T, 320, dtype=torch.float16, device=DEV)
+    ops.gemm(x, pack_tconv3(wt).to(DEV), out3, M=T, N=320, K=3 * 320, mode=ops.A_TCONV3, Cin=320, tconv=(2, H * W),
+             s_acc=0.5, res1=x, colstats=2 * H * W)
+    check(out3, nsamples=2, rows=2 * H * W)
+    _lib.lib().lkgd_debug_set_gemm_variant(0)
+    # plain linear with residual at K = 320 and 72k rows: the resident-weight program (32-row blocks); 640 rows per sample
+    M = 112 * 640
+    a = _h(torch.randn(M, 320, generator=g)).to(DEV)
+    wl = _h(torch.randn(320, 320, generator=g) / 320 ** 0.5).to(DEV)
+    res = _h(torch.randn(M, 320, generator=g)).to(DEV)
+    out4 = torch.empty(M, 320, dtype=torch.float16, device=DEV)
+    ops.gemm(a, wl, out4, M=M, N=320, K=320, bias=torch.randn(320, generator=g).to(DEV), res1=res, colstats=640)
+    assert out4._lkgd_colstats[1] == 32
+    check(out4, nsamples=112, rows=640)
+    # plain linear at K = 640 (256x320 program, rows through LDS), last tile ragged; samples of 256 rows
+    M = 256 * 13 + 0
+    a = _h(torch.randn(M, 640, generator=g)).to(DEV)
+    wl = _h(torch.randn(640, 640, generator=g) / 640 ** 0.5).to(DEV)
+    out5 = torch.empty(M, 640, dtype=torch.float16, device=DEV)
+    _lib.lib().lkgd_debug_set_gemm_variant(4)
+    try:
+        ops.gemm(a, wl, out5, M=M, N=640, K=640, res1=a, colstats=256)
+    finally:
+        _lib.lib().lkgd_debug_set_gemm_variant(0)
+    assert out5._lkgd_colstats[1] == 256
+    check(out5, nsamples=13, rows=256)
+    # a program without column sums (128x128 tiles: N = 64): nothing attached, the read pass runs
+    out6 = torch.empty(512, 64, dtype=torch.float16, device=DEV)
+    ops.gemm(a[:512], wl[:64], out6, M=512, N=64, K=640, colstats=256)
+    assert getattr(out6, "_lkgd_colstats", None) is None
