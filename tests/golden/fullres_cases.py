@@ -5,6 +5,7 @@ import torch
 FULLRES_SEED = 131        # seeds the INPUTS of the full-resolution fixtures (the stock UNet's weights are the c1 fixtures': seed 31)
 FULLRES_LK_SEED = 141     # LKGD UNet weights of the full-resolution LK + FSM-hook forward
 LOOP25_SEED = 151         # tiny-width 25-step loop
+F14_SEED = 161            # inputs of the 14-frame real-width loop fixtures (round 3)
 #: latent geometry of BASELINE.json configs[1] with 2 of the 14 frames: CFG batch 2 x 2 frames x 72 x 128 (S = 9216)
 FULLRES_GEOM = dict(B=2, F=2, H=72, W=128)
 

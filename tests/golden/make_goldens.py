@@ -696,7 +696,7 @@ def gen_loop_c1(pipe_mod, ref_stock, sched_mod):
     print("loop c1 real width: final std %.4f (2 steps)" % out["final"].std())
 
 
-from fullres_cases import (FULLRES_LK_SEED, FULLRES_SEED, LOOP25_SEED, fullres_inputs, fullres_tracks,   # noqa: E402
+from fullres_cases import (F14_SEED, FULLRES_LK_SEED, FULLRES_SEED, LOOP25_SEED, fullres_inputs, fullres_tracks,   # noqa: E402
                            seed_conv_fuse_)
 
 
@@ -888,6 +888,49 @@ def gen_loop25_c1(pipe_mod, ref_stock, sched_mod):
     print("loop25 c1 real width: final std %.4f" % out["final"].std())
 
 
+def gen_loop_f14(pipe_mod, ref_stock, sched_mod, guidance: bool):
+    """round 3: the reference `__call__` with the REAL-width UNet on ALL 14 frames of a clip at a 32 x 64 latent
+    (256 x 512 px; S = 2048 - every UNet level needs latent sides divisible by 8): 2 Euler steps, every step's latents stored - the 14-frame temporal attention, the F = 14
+    Conv3d chain and the temporal GroupNorm across 14 frames, end to end, and the oracle the (7,7) / (4,4,3,3) frame-sharded
+    runs are checked against.  guidance: CFG 1 -> 3 (batch 2 x 14) or guidance off (max_guidance_scale 1: batch 1 x 14, the
+    layout a 4-way frame split without CFG-parallel runs).  fp32 on the CPU: ~20 TFLOP per forward of the CFG batch."""
+    from oracle.unet import SVD_CONFIG
+    with torch.no_grad():
+        unet = ref_stock.UNetSpatioTemporalConditionControlNetModel(**SVD_CONFIG.__dict__)
+        ou.init_weights_(unet, C1_SEED)
+        for p in unet.parameters():
+            p.copy_(p.half().float())
+    g = torch.Generator().manual_seed(F14_SEED)
+    image = torch.rand(1, 3, 256, 512, generator=g)
+    lat0 = torch.randn(1, 14, 4, 32, 64, generator=g)
+    from oracle.scheduler import SchedulerConfig
+    sched = sched_mod.EulerDiscreteScheduler(**SchedulerConfig().__dict__)
+    fe = lambda images, **k: SimpleNamespace(pixel_values=images)   # noqa: E731
+    pipe = pipe_mod.StableVideoDiffusionPipeline(vae=_FakeVAE(), image_encoder=_FakeCLIP(), unet=unet, scheduler=sched,
+                                                 feature_extractor=fe)
+    rec, steps = {}, []
+    orig_forward = unet.forward
+
+    def spy(sample, t, **k):
+        if "enc" not in rec:
+            rec["enc"], rec["ids"] = k["encoder_hidden_states"].clone(), k["added_time_ids"].clone()
+            rec["image_latents"] = sample[:, :, 4:].clone()
+        y = orig_forward(sample, t, **k)
+        print("  step", len(steps), flush=True)
+        return y
+    unet.forward = spy
+    res = pipe(image, height=256, width=512, num_frames=14, num_inference_steps=2, latents=lat0.clone(),
+               min_guidance_scale=1.0, max_guidance_scale=3.0 if guidance else 1.0,
+               output_type="latent", generator=torch.Generator().manual_seed(F14_SEED + 1),
+               callback_on_step_end=lambda p_, i, t, kw_: (steps.append(kw_["latents"].clone()), {})[1])
+    out = {"latents0": lat0, "final": res.frames, "image_embeddings": rec["enc"], "added_time_ids": rec["ids"],
+           "image_latents": rec["image_latents"].contiguous(), "step_latents": torch.stack(steps),
+           "checksum": torch.tensor(checksum(unet), dtype=torch.float64)}
+    name = "loop_f14_cfg.safetensors" if guidance else "loop_f14_nocfg.safetensors"
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, name))
+    print("loop f14 (%s): final std %.4f" % ("cfg" if guidance else "no cfg", out["final"].std()))
+
+
 def gen_unet_fullres(ref_stock):
     """ONE forward of the reference's stock UNet (unet_spatio_temporal_condition_controlnet.py:358-508) at the REAL width
     and the FULL latent resolution of configs[1] (72 x 128, S = 9216) with CFG 2 x 2 frames, fp32 on the CPU"""
@@ -951,6 +994,14 @@ def main():
         _mod("patch")
         load_ref("patch/utils.py", "patch.utils")
         return gen_patch_lora(load_ref("patch/patch.py", "patch.patch"), ref_stock)
+    if only in ("loop_f14_cfg", "loop_f14_nocfg"):                              # round-3 fixtures
+        for m in ("models", "utils"):
+            _mod(m)
+        sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
+        ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
+                             "models.unet_spatio_temporal_condition_controlnet")
+        pipe_mod = load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans")
+        return gen_loop_f14(pipe_mod, ref_stock, sched_mod, only == "loop_f14_cfg")
     if only in ("loop25", "loop25_c1", "unet_fullres", "unet_fullres_lk"):     # round-2 fixtures, one at a time
         for m in ("models", "utils"):
             _mod(m)

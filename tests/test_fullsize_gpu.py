@@ -145,3 +145,97 @@ def test_full_size_loop_properties(full_pipe):
     # (3) more Euler steps on the same sigma schedule family stay finite and bounded
     f = _run(pipe, lat0, img, emb, ids, 4, 1.0, 3.0)
     assert torch.isfinite(f.float()).all() and f.float().abs().max() < 1e4
+
+
+def test_full_size_temporal_attention_and_layernorm_samples():
+    """round 3: the two hot ops the full-size suite only saw through loop properties - temporal attention over all F = 14 frames
+    at HW = 9216 (B = 2, 5 heads: 92 160 (pixel, head) problems) and LayerNorm over 258 048 rows - against fp32 on a strided
+    sample of pixels / rows"""
+    from lkgd_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(4)
+    B, Fr, HW, heads, C = 2, 14, H * W, 5, 320
+    qkv = torch.randn(T, 3 * C, device=DEV, generator=g).half()
+    out = torch.empty(T, C, dtype=torch.float16, device=DEV)
+    ops.attn_temporal(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, B, Fr, HW, heads)
+    pix = torch.arange(0, HW, 53, device=DEV)                                  # 174 pixels of each clip
+    x = qkv.reshape(B, Fr, HW, 3, heads, 64)[:, :, pix].float()                # [B, F, P, 3, h, 64]
+    q, k, v = (x[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))         # [B, P, h, F, 64]
+    ref = F.scaled_dot_product_attention(q, k, v)                              # over the 14 frames
+    got = out.reshape(B, Fr, HW, heads, 64)[:, :, pix].permute(0, 2, 3, 1, 4)
+    assert _rel(got, ref) < 3e-3
+    # LayerNorm (no affine: folded into the consumer) with the frame-position bias added before normalising
+    xln = (torch.randn(T, C, device=DEV, generator=g) * 2.0 + 0.7).half()
+    pos = torch.randn(Fr, C, device=DEV, generator=g).half()
+    y = ops.layernorm(xln, None, None, 1e-5, rowbias=pos, rowmap=ops.rowmap_div_mod(HW, Fr))
+    rows = torch.arange(0, T, 101, device=DEV)
+    xr = xln[rows].float() + pos[(rows // HW) % Fr].float()
+    assert _rel(y[rows], F.layer_norm(xr, (C,), None, None, 1e-5)) < 3e-3
+    y2 = ops.layernorm(xln, None, None, 1e-5)
+    assert _rel(y2[rows], F.layer_norm(xln[rows].float(), (C,), None, None, 1e-5)) < 3e-3
+
+
+def test_full_size_controlnet_loop_properties(full_pipe):
+    """BASELINE.json configs[3] at full size (14 frames x 576 x 1024, ControlNet-SVD encoder + LKGD UNet features on one GPU):
+    finite, bitwise deterministic, the condition really enters, CFG identity"""
+    from lkgd_amd import controlnet as pc
+    from lkgd_amd import unet as pu
+    pipe, (lat0, img, emb, ids) = full_pipe
+    dev = torch.device(DEV)
+    with torch.device("meta"):
+        cn = pc.ControlNetSDVModel(pu.UNetConfig(**{k: v for k, v in pipe.unet.config.__dict__.items()
+                                                    if k in pu.UNetConfig.__dataclass_fields__}))
+    cn = cn.to(torch.float16).to_empty(device=dev)
+    pu.init_synthetic_weights_(cn, seed=1)
+    pipe.controlnet = cn
+    try:
+        ctrl = (2.0 * torch.rand(1, 14, 3, 8 * H, 8 * W, generator=torch.Generator().manual_seed(12348)) - 1.0).half().to(dev)
+        ctrl2 = ctrl.repeat(2, 1, 1, 1, 1)
+        pipe.scheduler.set_timesteps(2)
+        s0 = float(pipe.scheduler.init_noise_sigma)
+        run = lambda i_, e_, c_, g_: pipe.denoise((lat0 * s0).half(), i_, e_, ids, 2, 1.0, g_, controlnet_condition=c_)  # noqa: E731
+        a = run(img, emb, ctrl2, 3.0)
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, run(img, emb, ctrl2, 3.0))
+        plain = pipe.denoise((lat0 * s0).half(), img, emb, ids, 2, 1.0, 3.0)
+        assert _rel(a, plain) > 1e-2                       # the ControlNet residuals change the result
+        img_same, emb_same = torch.cat([img[1:], img[1:]]), torch.cat([emb[1:], emb[1:]])
+        c = run(img_same, emb_same, ctrl2, 3.0)
+        d = run(img_same, emb_same, ctrl2, 7.5)
+        assert _rel(c, d) < 2e-3                           # cond == uncond: the guidance scale is irrelevant
+    finally:
+        pipe.controlnet = None
+        del cn
+        torch.cuda.empty_cache()
+
+
+def test_full_size_cogvideox_forward_and_ddim_steps():
+    """BASELINE.json configs[4] at full size: the 30-layer CogVideoX-2B DiT on 17 776 joint tokens (49 frames x 480 x 720 ->
+    13 x 60 x 90 latents, 226 text tokens), one CFG-batch forward and 2 DDIM steps: finite, bitwise deterministic, CFG
+    identity (equal prompt embeddings make the guidance scale irrelevant)"""
+    from lkgd_amd import cogvideox as pc
+    from lkgd_amd import unet as pu
+    dev = torch.device(DEV)
+    cfg = pc.DiTConfig(in_channels=32)
+    with torch.device("meta"):
+        m = pc.CogVideoXTransformer3DModel(cfg)
+    m = m.to(torch.float16).to_empty(device=dev)
+    pu.init_synthetic_weights_(m, seed=0)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if ".linear." in n and ("norm1" in n or "norm2" in n or "norm_out" in n):
+                p.mul_(0.1)
+    g = torch.Generator().manual_seed(3)
+    f = (cfg.sample_frames - 1) // cfg.temporal_compression_ratio + 1
+    assert f * (cfg.sample_height // 2) * (cfg.sample_width // 2) + cfg.max_text_seq_length == 17776
+    lat = torch.randn(1, f, 16, cfg.sample_height, cfg.sample_width, generator=g).half().to(dev)
+    img = (0.5 * torch.randn(1, f, 16, cfg.sample_height, cfg.sample_width, generator=g)).half().to(dev)
+    pe = torch.randn(2, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g).half().to(dev)
+    dom, flow = torch.randn(1, 1, 1000, generator=g).to(dev), torch.randn(1, 1, 1000, generator=g).to(dev)
+    run = lambda pe_, gs: pc.denoise(m, pc.CogVideoXDDIMScheduler(), lat, img, pe_, dom, flow, 2, gs, True)   # noqa: E731
+    a = run(pe, 6.0)
+    assert a.shape == lat.shape and torch.isfinite(a.float()).all() and a.float().abs().max() < 1e3
+    assert torch.equal(a, run(pe, 6.0))
+    same = torch.cat([pe[1:], pe[1:]])
+    assert _rel(run(same, 6.0), run(same, 2.0)) < 2e-3
+    del m
+    torch.cuda.empty_cache()
