@@ -182,6 +182,16 @@ int lkgd_attn_temporal(const void* q, int32_t ldq, const void* k, int32_t ldk, c
                        void* out, int32_t ldo, int32_t B, int32_t Fq, int32_t Fk, int32_t S, int32_t heads,
                        const int32_t* kv_b_map, float scale, lkgd_stream_t stream);
 
+/* 5b. Fused temporal-attention front: out = attn1(norm1(x)) without its out-projection - LayerNorm (no affine: folded into
+ *    the weights), the Q|K|V projection and the attention over the F frames of every (pixel, head) in one kernel; the
+ *    normalised tokens and the Q|K|V rows never reach HBM.  C = 320 channels = heads x 64, F <= 16, HW % 16 == 0.
+ *    wpack = the fused [3C, C] projection (rows q | k | v, head-major) re-laid as MFMA fragments:
+ *    [head][q,k,v][4 fragments of 16 rows][10 K-steps of 32][lane = 16*(k/8 % 4) + row % 16][8]  (lkgd_amd/packing.py::
+ *    pack_tfront); bqkv = fp32 [3C] or NULL.  Replaces, per temporal block: F.layer_norm + three F.linear + SDPA and the
+ *    [B*F,S,C] <-> [B*S,F,C] regroups (patch/patch.py:592-597, :610, :660-661). */
+int lkgd_tattn_front(const void* x, int32_t ldx, const void* wpack, const float* bqkv, void* out, int32_t ldo, int32_t B,
+                     int32_t F, int32_t HW, int32_t heads, float eps, float scale, lkgd_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * 6. Loop glue (pipeline_stable_video_diffusion_trans.py:549-553, :578-592; scheduler :264-288, :418-528).
  *    lkgd_prepare_unet_input: latents fp16/fp32 [B,F,4,H,W] -> CFG duplicate, divide by sqrt(sigma^2+1), concat

@@ -289,6 +289,23 @@ def attn_temporal(q, k, v, out, B: int, F: int, S: int, heads: int, kv_b_map: Op
     return out
 
 
+def tattn_front(x: torch.Tensor, wpack: torch.Tensor, bqkv: Optional[torch.Tensor], out: torch.Tensor, B: int, F: int, HW: int,
+                heads: int, eps: float = 1e-5, scale: float = 0.125) -> torch.Tensor:
+    """out = attn1(LayerNorm(x)) without the out-projection, fused (include/lkgd_hip.h section 5b); x / out: [B*F*HW, 320]"""
+    _req(x, torch.float16, "x"); _req(wpack, torch.float16, "wpack"); _req(out, torch.float16, "out")
+    check(_L().lkgd_tattn_front(x.data_ptr(), _ld(x), wpack.data_ptr(), _ptr(bqkv), out.data_ptr(), _ld(out), B, F, HW, heads,
+                                eps, scale, _stream()), "lkgd_tattn_front")
+    return out
+
+
+def tattn_front_ok(C_: int, heads: int, F: int, HW: int) -> bool:
+    return TFRONT and C_ == 320 and heads * 64 == C_ and 1 <= F <= 16 and HW % 16 == 0
+
+
+#: A/B switch of the fused temporal-attention front (False = LayerNorm, QKV GEMM and attention kernel as three launches)
+TFRONT = os.environ.get("LKGD_NO_TFRONT", "0") != "1"
+
+
 def attn_cross(q, k, v, out, heads: int, ncontexts: int, Lk: int, rowmap: RowMap, scale: float = 0.125):
     """rows of q against the Lk keys of context rowmap(row); k / v: [ncontexts * Lk, heads * 64] (lkgd_hip.h section 15)"""
     _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v"); _req(out, torch.float16, "out")

@@ -37,6 +37,15 @@ def pack_tconv3(w: torch.Tensor) -> torch.Tensor:
     return w[:, :, :, 0, 0].permute(0, 2, 1).reshape(co, 3 * ci).to(torch.float16).contiguous()
 
 
+def pack_tfront(wqkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """fused projection [3C, C] (rows q | k | v, head-major) -> the MFMA-fragment stream of lkgd_tattn_front:
+    [head][q,k,v][fragment i of 16 rows][K-step ks of 32][lane = 16*lq + row][8 halfs at k = 32 ks + 8 lq]"""
+    c3, c = wqkv.shape
+    assert c3 == 3 * c and c == heads * 64 and c % 32 == 0
+    t = wqkv.to(torch.float16).reshape(3, heads, 4, 16, c // 32, 4, 8)      # [which, h, i, row, ks, lq, e]
+    return t.permute(1, 0, 2, 4, 5, 3, 6).contiguous().reshape(-1)
+
+
 def geglu_perm(inner: int, half: int = 32, device=None) -> torch.Tensor:
     """row permutation of the GEGLU projection [2*inner, K]: every 2*half packed rows = `half` hidden rows followed by
     their `half` gate rows (inner + ..), so that the output columns one wave owns hold both factors of its GEGLU

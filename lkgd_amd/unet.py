@@ -521,10 +521,19 @@ class TemporalBasicTransformerBlock(nn.Module):
         fmap = ops.rowmap_div_mod(ctx.HW, ctx.F)
         lnin = ops.layernorm(h_s, None, None, 1e-5, rowbias=posemb, rowmap=fmap)
         m1 = _ff(ctx, pk.ffin, lnin, res1=h_s, rowbias=posemb, rowmap=fmap)        # ff_in(norm_in(m0)) + m0
-        ln1 = ops.layernorm(m1, None, None, 1e-5)
         att = ctx.new(T, Cc)
         va = None
-        if ctx.lora is not None:
+        # LayerNorm + QKV + attention over the frames in one kernel where it exists (C = 320: the 72x128 level); the joint
+        # branch reads the normalised tokens again, masked LoRA runs per-entry weights, a sharded rank gathers frames: unfused
+        fused = (ctx.lora is None and not ctx.frames_sharded and ops.tattn_front_ok(Cc, self.attn1.heads, ctx.F, ctx.HW) and
+                 not (self.enable_joint_attention and hasattr(self, "attn1n")))
+        ln1 = None if fused else ops.layernorm(m1, None, None, 1e-5)
+        if fused:
+            if getattr(pk.a1, "wfront", None) is None:
+                from .packing import pack_tfront
+                pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
+            ops.tattn_front(m1, pk.a1.wfront, pk.a1.bqkv, att, ctx.B, ctx.F, ctx.HW, self.attn1.heads)
+        elif ctx.lora is not None:
             if ctx.frames_sharded:
                 raise LkgdHipError("masked LoRA is not available under frame sharding")
             va = [_attn_variant(self, "a1", ctx, i, False) for i in range(len(ctx.lora.runs))]

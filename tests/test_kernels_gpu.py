@@ -812,3 +812,34 @@ def test_groupnorm_statistics_from_gemm_epilogues():
     out6 = torch.empty(512, 64, dtype=torch.float16, device=DEV)
     ops.gemm(a[:512], wl[:64], out6, M=512, N=64, K=640, colstats=256)
     assert getattr(out6, "_lkgd_colstats", None) is None
+
+
+@pytest.mark.parametrize("B,Fr,HW", [(2, 14, 48), (1, 16, 16), (3, 5, 1024), (2, 1, 32)])
+def test_temporal_attention_front_fused(B, Fr, HW):
+    """lkgd_tattn_front: LayerNorm + Q|K|V projection + attention over the frames of every (pixel, head) in one kernel, against
+    fp32 (F.layer_norm -> F.linear -> SDPA over the frame axis) and against the three-launch HIP form; several panels per
+    workgroup at HW = 1024, frame counts 1 / 5 / 14 / 16 (masked keys, padded rows)"""
+    from lkgd_amd import ops
+    from lkgd_amd.packing import pack_linear, pack_tfront
+    g = torch.Generator().manual_seed(100 * B + Fr)
+    C, heads = 320, 5
+    T = B * Fr * HW
+    x = _h(torch.randn(T, C, generator=g) * 1.7 + 0.4)
+    w = torch.randn(3 * C, C, generator=g) / C ** 0.5
+    b = torch.randn(3 * C, generator=g) * 0.2
+    wh = _h(w)
+    xn = F.layer_norm(x.float(), (C,), None, None, 1e-5)
+    qkv = xn @ wh.float().T + b
+    q, k, v = (t.reshape(B, Fr, HW, heads, 64).permute(0, 2, 3, 1, 4) for t in qkv.chunk(3, dim=-1))     # [B, HW, h, F, 64]
+    ref = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(T, C)
+    out = torch.full((T, C), float("nan"), dtype=torch.float16, device=DEV)
+    ops.tattn_front(x.to(DEV), pack_tfront(wh, heads).to(DEV), b.to(DEV), out, B, Fr, HW, heads)
+    _close(out, ref, what=f"fused temporal front B={B} F={Fr} HW={HW}")
+    # the unfused HIP form of the same block front
+    xd = x.to(DEV)
+    ln = ops.layernorm(xd, None, None, 1e-5)
+    qkv_d = torch.empty(T, 3 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(ln, pack_linear(wh).to(DEV), qkv_d, M=T, N=3 * C, K=C, bias=b.to(DEV))
+    att = torch.empty(T, C, dtype=torch.float16, device=DEV)
+    ops.attn_temporal(qkv_d[:, :C], qkv_d[:, C:2 * C], qkv_d[:, 2 * C:], att, B, Fr, HW, heads)
+    assert ((out.float() - att.float()).norm() / att.float().norm()).item() < 3e-3
