@@ -22,6 +22,18 @@
 //   * the head's 64 output channels of the wave's 32 rows leave through a wave-private LDS patch as 16-byte pieces of
 //     128-byte row segments.
 #include "common.h"
+
+// timing-experiment knobs (tools/micro/tfront_knobs.sh; results are wrong with any of them): never defined in the product build
+#ifdef TF_X_NOMFMA
+#define TF_MM(X) ""
+#else
+#define TF_MM(X) X
+#endif
+#ifdef TF_X_NOREAD
+#define TF_RD(X) ""
+#else
+#define TF_RD(X) X
+#endif
 #include "attn_tfront_kloop.inc"
 
 #define TF_NT 512
@@ -31,7 +43,8 @@
 #define TF_STAGES 3
 #define TF_PATCH_PITCH 144            // bytes per staged output row (128 + 16)
 #define TF_PATCH (32 * TF_PATCH_PITCH)
-#define TF_LDS (TF_STAGES * TF_CHUNK_BYTES + TF_WAVES * TF_PATCH)
+#define TF_BIAS_BYTES (3 * TF_C * 4)   // the projection bias, staged once (a global load at its use would expose an L2 round trip per chunk)
+#define TF_LDS (TF_STAGES * TF_CHUNK_BYTES + TF_WAVES * TF_PATCH + TF_BIAS_BYTES)
 
 template <int REG>
 __device__ __forceinline__ unsigned tf_agpr_read() {
@@ -107,6 +120,7 @@ __global__ __launch_bounds__(TF_NT, 2) __attribute__((amdgpu_num_vgpr(144))) voi
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   char* patch = smem + TF_STAGES * TF_CHUNK_BYTES + w * TF_PATCH;
+  float* bias_l = (float*)(smem + TF_STAGES * TF_CHUNK_BYTES + TF_WAVES * TF_PATCH);
   const int nchunk = heads * 3;
   const int my_panels = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   if (my_panels <= 0) return;
@@ -118,19 +132,39 @@ __global__ __launch_bounds__(TF_NT, 2) __attribute__((amdgpu_num_vgpr(144))) voi
     const char* src = (const char*)wpack + (long long)c * TF_CHUNK_BYTES + t * 16;
     char* dst = smem + (int)(g % TF_STAGES) * TF_CHUNK_BYTES + w * 1024;
 #pragma unroll
-    for (int r = 0; r < 5; ++r) glds16(src + r * 8192, dst + r * 8192);
+    for (int r = 0; r < 5; ++r) {
+#ifndef TF_X_NODMA
+      glds16(src + r * 8192, dst + r * 8192);
+#endif
+    }
   };
   issue_chunk(0);
   if (total > 1) issue_chunk(1);
+  for (int i = t; i < 3 * TF_C; i += TF_NT) bias_l[i] = bqkv ? bqkv[i] : 0.f;
+  __syncthreads();
 
   const int fcl = l15 < F ? l15 : F - 1;            // frame of this lane's token rows (rows >= F repeat the last frame: masked / not stored)
   half8_t qp[2][2], kp[2][2];                        // head channels x tokens, fp16 MFMA operands: [k-step of 32 channels][token fragment]
   long long g = 0;
+#ifdef TF_X_STAMPS      // diagnostic build (tools/micro/tfront_stamps.py): s_memtime sums per wave, written over the first output rows
+  long long st_sync = 0, st_mm = 0, st_e[3] = {0, 0, 0}, st_pro = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+#define TF_STAMP(X) X = __builtin_amdgcn_s_memtime()
+#else
+#define TF_STAMP(X)
+#endif
 #pragma unroll 1
   for (int pi = 0; pi < my_panels; ++pi) {
+    TF_STAMP(st_a);
     const int panel = (int)blockIdx.x + pi * (int)gridDim.x;
     const int b = panel / panels_per_clip;
     const int p0 = (panel - b * panels_per_clip) * 16 + 2 * w;
+    // this lane's four output rows (piece q = lane + 64 kk -> row q >> 3 = 8 kk + lane / 8, column piece q & 7) at head 0
+    half_t* dstp[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int row = 8 * kk + (lane >> 3), j = row >> 4, f = row & 15;
+      dstp[kk] = out + ((long long)(b * F + (f < F ? f : F - 1)) * HW + p0 + j) * ldo + (lane & 7) * 8;
+    }
     // ---- token rows of the wave's two pixels -> a[32:111]
     {
       const half_t* r0 = x + ((long long)(b * F + fcl) * HW + p0) * ldx + lq * 8;
@@ -184,6 +218,9 @@ __global__ __launch_bounds__(TF_NT, 2) __attribute__((amdgpu_num_vgpr(144))) voi
         }
       }
     }
+#ifdef TF_X_STAMPS
+    st_b = __builtin_amdgcn_s_memtime(); st_pro += st_b - st_a;
+#endif
 #pragma unroll 1
     for (int h = 0; h < heads; ++h) {
       half8_t pp[2];                                  // probabilities of the two pixels: this lane's 4 keys + 4 zero k-slots
@@ -192,22 +229,35 @@ __global__ __launch_bounds__(TF_NT, 2) __attribute__((amdgpu_num_vgpr(144))) voi
         // chunk g has landed (this thread's loads; the barrier publishes everyone's); every wave is done with chunk g-1,
         // whose stage takes chunk g+2.  Issued after chunk g's loads (at the top of iteration g-2): the four row-piece stores
         // of iteration g-2 when that was a v chunk (this is a k chunk), chunk g+1's five loads, the four stores of iteration
-        // g-1 when that was a v chunk (this is a q chunk) - 9 operations may stay in flight at a q / k chunk, 5 at a v chunk
+        // g-1 when that was a v chunk (this is a q chunk) - 9 operations may stay in flight at a q / k chunk, 5 at a v chunk.
+        // Only the stores with a live lane are counted (F <= 8 leaves the two that hold frames 8.. without one).
+        TF_STAMP(st_a);
         if (g + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stream's last chunk: nothing behind it
         else if (which == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");    // (first head of a panel: the panel start drained everything)
+        else if (F > 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");    // (first head of a panel: the panel start drained everything)
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (g + 2 < total) issue_chunk(g + 2);
         const int wl = (int)(g % TF_STAGES) * TF_CHUNK_BYTES + lane * 16;
-        const float* bias = bqkv ? bqkv + which * TF_C + h * 64 : nullptr;
+        const float* bias = bias_l + which * TF_C + h * 64;
+#ifdef TF_X_STAMPS
+        st_b = __builtin_amdgcn_s_memtime(); st_sync += st_b - st_a;
+        if (which < 2) tf_chunk<false>(wl); else tf_chunk<true>(wl);
+        st_a = __builtin_amdgcn_s_memtime(); st_mm += st_a - st_b;
+#endif
+#ifdef TF_X_NOEPI
+        if (which < 2) tf_chunk<false>(wl); else tf_chunk<true>(wl);
+        if (lane < 0)          // never true: the epilogues stay compiled, nothing runs
+#endif
         if (which < 2) {
+#if !defined(TF_X_NOEPI) && !defined(TF_X_STAMPS)
           tf_chunk<false>(wl);
+#endif
           // acc[d][token] + bias[d] -> fp16 (q also times softmax scale * log2 e)
           const float sc = which == 0 ? qscale : 1.0f;
           tf_for4([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            float4_t bb = {0.f, 0.f, 0.f, 0.f};
-            if (bias) bb = *(const float4_t*)(bias + i * 16 + 4 * lq);
+            const float4_t bb = *(const float4_t*)(bias + i * 16 + 4 * lq);
             tf_static_for([&](auto jc) {
               constexpr int j = decltype(jc)::value;
               const float4_t v = (tf_read_acc<(2 * i + j) * 4>() + bb) * sc;
@@ -242,13 +292,15 @@ __global__ __launch_bounds__(TF_NT, 2) __attribute__((amdgpu_num_vgpr(144))) voi
             }
           }
         } else {
+#if !defined(TF_X_NOEPI) && !defined(TF_X_STAMPS)
           tf_chunk<true>(wl);
+#endif
           // acc[token][d] (lane = head channel d = 16i + l15, 4 tokens 4lq..) + bias[d] -> fp16 k-slots of O = V^T . P
           // (every accumulator is read before the first attention MFMA below: see tf_mfma)
           half8_t vp[4][2];
           tf_for4([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const float bb = bias ? bias[i * 16 + l15] : 0.f;
+            const float bb = bias[i * 16 + l15];
             const float4_t v0 = tf_read_acc<(2 * i) * 4>() + bb, v1 = tf_read_acc<(2 * i + 1) * 4>() + bb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -271,17 +323,27 @@ __global__ __launch_bounds__(TF_NT, 2) __attribute__((amdgpu_num_vgpr(144))) voi
             const int q = lane + 64 * kk;
             const int row = q >> 3, cc = q & 7;
             const half8_t v = *(const half8_t*)(patch + row * TF_PATCH_PITCH + cc * 16);
-            const int j = row >> 4, f = row & 15;
-            half_t* dst = out + ((long long)(b * F + (f < F ? f : F - 1)) * HW + p0 + j) * ldo + h * 64 + cc * 8;
+            const int f = row & 15;
+            half_t* dst = dstp[kk] + h * 64;
             unsigned long long sv;
             asm volatile("v_cmp_gt_i32 vcc, %3, %4\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_store_dwordx4 %1, %2, off\n\ts_mov_b64 exec, %0\n\ts_nop 1"
                          : "=&s"(sv) : "v"(dst), "v"(v), "s"(F), "v"(f) : "vcc", "memory");
           }
         }
+#ifdef TF_X_STAMPS
+        st_e[which] += __builtin_amdgcn_s_memtime() - st_a;
+#endif
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TF_X_STAMPS
+  if (lane == 0) {
+    long long* dbg = (long long*)out + ((long long)blockIdx.x * TF_WAVES + w) * 8;
+    dbg[0] = st_pro; dbg[1] = st_sync; dbg[2] = st_mm; dbg[3] = st_e[0]; dbg[4] = st_e[1]; dbg[5] = st_e[2];
+    dbg[6] = __builtin_amdgcn_s_memtime() - st_t0; dbg[7] = my_panels;
+  }
+#endif
 }
 
 extern "C" int lkgd_tattn_front(const void* x, int32_t ldx, const void* wpack, const float* bqkv, void* out, int32_t ldo, int32_t B,
