@@ -167,13 +167,25 @@ def vae_stages(dev, args, latents, loop_s_per_clip):
         return (time.perf_counter() - t0) / reps, r
     t_enc, _ = timed(lambda: v.encode(img).latent_dist.mode())
     t_dec, frames = timed(lambda: v.decode(z, num_frames=args.frames).sample)
-    total = loop_s_per_clip + t_enc + t_dec
-    return {"vae_encode_ms": round(t_enc * 1e3, 2), "vae_decode_ms": round(t_dec * 1e3, 2),
+    # the CLIP image encoder of `image_encoder/` (ViT-H/14, random init) on the HIP path: lkgd_amd/clip.py
+    from lkgd_amd import clip as pc
+    with torch.device("meta"):
+        enc = pc.CLIPVisionModelWithProjection()
+    enc = enc.to(torch.float16).to_empty(device=dev)
+    pu.init_synthetic_weights_(enc, seed=3)
+    with torch.no_grad():
+        enc.vision_model.embeddings.position_embedding.weight.normal_(0, 0.02)
+        enc.vision_model.embeddings.class_embedding.normal_(0, 0.02)
+    pix = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(7)).to(dev)
+    t_clip, emb = timed(lambda: enc(pix).image_embeds)
+    total = loop_s_per_clip + t_enc + t_dec + t_clip
+    return {"clip_encode_ms": round(t_clip * 1e3, 2), "clip_finite": bool(torch.isfinite(emb.float()).all().item()),
+            "vae_encode_ms": round(t_enc * 1e3, 2), "vae_decode_ms": round(t_dec * 1e3, 2),
             "decode_chunk_size": args.frames, "decoded": list(frames.shape),
             "finite": bool(torch.isfinite(frames.float()).all().item()),
             "videos_per_s": round(1.0 / total, 4), "frames_per_s": round(args.frames / total, 4),
-            "note": "loop + VAE encode + temporal VAE decode of one clip (CLIP image encoder not included); untimed extras, "
-                    "the headline value is the loop alone"}
+            "note": "CLIP-ViT-H image embedding + VAE encode + loop + temporal VAE decode of one clip, all on the HIP path; "
+                    "untimed extras, the headline value is the loop alone"}
 
 
 def self_launch(args) -> int:

@@ -340,6 +340,17 @@ int lkgd_attn_cross(const void* q, int32_t ldq, const void* k, int32_t ldk, cons
                     int64_t T, int32_t heads, int32_t ncontexts, int32_t Lk, int32_t rb_d1, int32_t rb_m1, int32_t rb_d2,
                     int32_t rb_md, int32_t rb_c0, float scale, lkgd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * 16. Dense self-attention for short sequences, any head_dim <= 128 (multiple of 8): the attention of the CLIP-ViT-H image
+ *     encoder (`self.image_encoder(image).image_embeds`, pipeline/pipeline_stable_video_diffusion_trans.py:164-203 - 257 tokens,
+ *     16 heads of 80 channels [EXT transformers CLIPAttention]).  q, k, v, out: [nbatch*S, heads*head_dim] token rows (row
+ *     strides in halfs), softmax(q k^T * scale) v per (batch entry, head), fp32 arithmetic.  K and V of one head must fit the
+ *     CU's LDS: 2 * S * (head_dim + 2) * 2 + 16 * S + 1024 <= 163840 bytes, else LKGD_E_SHAPE (longer sequences at head_dim 64:
+ *     lkgd_attn_spatial).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_attn_dense(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out, int32_t ldo,
+                    int32_t nbatch, int32_t S, int32_t heads, int32_t head_dim, float scale, lkgd_stream_t stream);
+
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
 

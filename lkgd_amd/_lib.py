@@ -83,6 +83,7 @@ SYMBOLS = {
     "lkgd_euler_step": (_i32, [_vp, _vp, _i32, _vp, _i64, _f32, _f32, _i32, _vp]),
     "lkgd_attn_cross": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                 _f32, _vp]),
+    "lkgd_attn_dense": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "lkgd_euler_step_churn": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "lkgd_fsm_rows": (_i32, [C.POINTER(FsmDesc), _vp]),
     "lkgd_conv3x3_small": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),

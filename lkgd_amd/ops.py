@@ -316,6 +316,16 @@ def attn_cross(q, k, v, out, heads: int, ncontexts: int, Lk: int, rowmap: RowMap
     return out
 
 
+def attn_dense(q, k, v, out, nbatch: int, S: int, heads: int, head_dim: int, scale: Optional[float] = None):
+    """short-sequence attention with any head_dim <= 128 (lkgd_hip.h section 16): q, k, v, out [nbatch*S, heads*head_dim]"""
+    _req(q, torch.float16, "q"); _req(k, torch.float16, "k"); _req(v, torch.float16, "v"); _req(out, torch.float16, "out")
+    if scale is None:
+        scale = head_dim ** -0.5
+    check(_L().lkgd_attn_dense(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(), _ld(out),
+                               nbatch, S, heads, head_dim, scale, _stream()), "lkgd_attn_dense")
+    return out
+
+
 def prepare_unet_input(latents: torch.Tensor, image_latents: torch.Tensor, cfg: int, sigma: float,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[B,F,4,H,W] latents (+ [cfg*B,F,4,H,W] image latents) -> channels-last tokens [cfg*B*F*H*W, 8]"""

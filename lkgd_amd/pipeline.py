@@ -81,8 +81,8 @@ class StableVideoDiffusionPipeline:
                         unet=None, vae=None, image_encoder=None, feature_extractor=None, scheduler=None, controlnet=None,
                         unet_class=None, device: Optional[str] = "cuda", **_ignored):
         """a local diffusers pipeline directory (``unet/ vae/ image_encoder/ feature_extractor/ scheduler/``).  The UNet,
-        the VAE and the scheduler are lkgd_amd's own classes; CLIP (`image_encoder`, `feature_extractor`) is a boundary
-        stage and comes from `transformers` when that package is importable and the folders exist.  Components passed
+        the VAE, the scheduler and the CLIP image encoder (`image_encoder/` -> lkgd_amd.clip, transformers' parameter names;
+        `feature_extractor/` -> its mean / std normalisation) are lkgd_amd's own classes: no diffusers, no transformers.  Components passed
         as keywords are used as given (``unet=...`` as utils/util.py:607-616 does).  hub / offload keywords are accepted
         and ignored (``low_cpu_mem_usage``, ``device_map``, ``local_files_only`` ...)."""
         import os
@@ -102,20 +102,12 @@ class StableVideoDiffusionPipeline:
         if scheduler is None and has("scheduler", "scheduler_config.json"):
             scheduler = EulerDiscreteScheduler.from_pretrained(root, subfolder="scheduler")
         if image_encoder is None and has("image_encoder", "config.json"):
-            try:
-                from transformers import CLIPVisionModelWithProjection
-            except ImportError as e:
-                raise LkgdHipError("image_encoder/ needs `transformers` (CLIPVisionModelWithProjection); pass "
-                                   "`image_embeddings=` to __call__ instead") from e
-            try:                      # transformers >= 4.56 spells the keyword `dtype`, older releases `torch_dtype`
-                image_encoder = CLIPVisionModelWithProjection.from_pretrained(os.path.join(root, "image_encoder"),
-                                                                              dtype=torch_dtype)
-            except TypeError:
-                image_encoder = CLIPVisionModelWithProjection.from_pretrained(os.path.join(root, "image_encoder"),
-                                                                              torch_dtype=torch_dtype)
+            from .clip import CLIPVisionModelWithProjection          # transformers' class name and checkpoint layout, HIP forward
+            image_encoder = CLIPVisionModelWithProjection.from_pretrained(root, subfolder="image_encoder",
+                                                                          torch_dtype=torch_dtype, variant=variant)
         if feature_extractor is None and has("feature_extractor", "preprocessor_config.json"):
-            from transformers import CLIPImageProcessor
-            feature_extractor = CLIPImageProcessor.from_pretrained(os.path.join(root, "feature_extractor"))
+            from .clip import CLIPImageProcessor
+            feature_extractor = CLIPImageProcessor.from_pretrained(root, subfolder="feature_extractor")
         pipe = cls(vae=vae, image_encoder=image_encoder, unet=unet, scheduler=scheduler,
                    feature_extractor=feature_extractor, controlnet=controlnet)
         return pipe.to(device) if device is not None else pipe

@@ -108,8 +108,9 @@ def update_unet_from_lora_file(unet, lora_weights_path: str) -> List[str]:
 
 def make_tiny_pipeline_dir(path: str, seed: int = 0) -> str:
     """a random-init pipeline directory in the diffusers layout with tiny components (plumbing checks on boxes without
-    checkpoints): lkgd_amd UNet / VAE / scheduler + a one-layer CLIP vision tower from `transformers`"""
-    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
+    checkpoints): lkgd_amd UNet / VAE / scheduler + a one-layer CLIP vision tower in transformers' on-disk layout"""
+    import json
+    from .clip import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
     from . import unet as pu
     from . import vae as pv
     from .scheduler import EulerDiscreteScheduler
@@ -125,10 +126,17 @@ def make_tiny_pipeline_dir(path: str, seed: int = 0) -> str:
     EulerDiscreteScheduler.from_svd_config().save_pretrained(os.path.join(path, "scheduler"))
     clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1,
                                                           num_attention_heads=2, image_size=224, patch_size=32,
-                                                          projection_dim=1024))
+                                                          projection_dim=1024, hidden_act="quick_gelu"))
+    pu.init_synthetic_weights_(clip, seed + 2)
+    with torch.no_grad():
+        clip.vision_model.embeddings.position_embedding.weight.normal_(0, 0.02)
+        clip.vision_model.embeddings.class_embedding.normal_(0, 0.02)
     clip.half().save_pretrained(os.path.join(path, "image_encoder"))
-    CLIPImageProcessor(size={"shortest_edge": 224}, crop_size={"height": 224, "width": 224}).save_pretrained(
-        os.path.join(path, "feature_extractor"))
+    os.makedirs(os.path.join(path, "feature_extractor"), exist_ok=True)
+    with open(os.path.join(path, "feature_extractor", "preprocessor_config.json"), "w") as fh:
+        json.dump({"image_processor_type": "CLIPImageProcessor", "do_normalize": True, "image_mean": list(CLIPImageProcessor.OPENAI_MEAN),
+                   "image_std": list(CLIPImageProcessor.OPENAI_STD), "size": {"shortest_edge": 224},
+                   "crop_size": {"height": 224, "width": 224}}, fh, indent=2)
     return path
 
 

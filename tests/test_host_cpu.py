@@ -260,3 +260,46 @@ def test_resident_weight_kernel_has_no_register_spills():
     assert len(kernels) >= 30, len(kernels)
     bad = [k for k in kernels if k[1] or k[2]]
     assert not bad, bad
+
+
+def test_clip_module_takes_transformers_state_dict_names(tmp_path):
+    """lkgd_amd.clip keeps transformers' parameter names (image_encoder/ checkpoints load as they are), round-trips through
+    save_pretrained / from_pretrained, ignores the persisted position_ids of older checkpoints, and refuses to run off the GPU"""
+    import json
+    import pytest
+    import torch
+    from safetensors.torch import load_file, save_file
+    from lkgd_amd._lib import LkgdHipError
+    from lkgd_amd.clip import CLIPVisionConfig, CLIPVisionModelWithProjection
+    cfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, patch_size=14,
+                           image_size=28, projection_dim=64)
+    m = CLIPVisionModelWithProjection(cfg)
+    names = set(m.state_dict())
+    want = {"vision_model.embeddings.class_embedding", "vision_model.embeddings.patch_embedding.weight",
+            "vision_model.embeddings.position_embedding.weight", "vision_model.pre_layrnorm.weight", "vision_model.pre_layrnorm.bias",
+            "vision_model.post_layernorm.weight", "vision_model.post_layernorm.bias", "visual_projection.weight"}
+    for i in range(2):
+        for lin in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "mlp.fc1", "mlp.fc2",
+                    "layer_norm1", "layer_norm2"):
+            want |= {f"vision_model.encoder.layers.{i}.{lin}.weight", f"vision_model.encoder.layers.{i}.{lin}.bias"}
+    assert names == want
+    try:
+        import transformers
+        c = transformers.CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                          patch_size=14, image_size=28, projection_dim=64, hidden_act="gelu")
+        assert set(transformers.CLIPVisionModelWithProjection(c).state_dict()) == names
+    except ImportError:
+        pass
+    d = tmp_path / "image_encoder"
+    m.save_pretrained(str(d))
+    sd = load_file(str(d / "model.safetensors"))
+    sd["vision_model.embeddings.position_ids"] = torch.arange(5)[None]
+    save_file(sd, str(d / "model.safetensors"))
+    assert json.load(open(d / "config.json"))["hidden_size"] == 128
+    m2 = CLIPVisionModelWithProjection.from_pretrained(str(d), torch_dtype=torch.float32)
+    for k, v in m.state_dict().items():
+        assert torch.equal(m2.state_dict()[k], v)
+    with pytest.raises(LkgdHipError):
+        m2(torch.zeros(1, 3, 28, 28))
+    with pytest.raises(LkgdHipError):
+        CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=128, num_attention_heads=2, hidden_act="relu"))
