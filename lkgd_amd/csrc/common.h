@@ -30,6 +30,9 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 // t = 1/(1 + p|x|/sqrt2)  (no sign select, no 1 +- erf), everything but rcp/exp2 on float2 (v_pk_fma_f32 / v_pk_mul_f32).
 typedef float float2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2_t gelu_erf2(float2_t x) {
+#if defined(LKGD_X_GELU_NONE)        /* timing experiment only (tools/micro/gelu_knobs.sh): what the erf arithmetic costs */
+  return x;
+#endif
   const float2_t ax = __builtin_elementwise_abs(x);
   const float2_t d = __builtin_elementwise_fma(ax, (float2_t)(0.3275911f * 0.70710678118654752440f), (float2_t)(1.0f));
   const float2_t z = ax * 0.84932180028801904272f;          // z^2 = (x^2 / 2) * log2(e)
