@@ -21,7 +21,9 @@
 #ifndef ATT_KVB16
 #define ATT_KVB16 128        // keys per barrier of the 16-wave kernel
 #endif
-#define ATT_NST 2           // LDS stages of KVB keys each (K image + V image per stage)
+#ifndef ATT_NST
+#define ATT_NST 2           // LDS stages of KVB keys each (K image + V image per stage); 3 = the loads get two tiles of flight time
+#endif
 #define ATT_THR 5.0f        // the running reference max moves only when a score exceeds it by more than this (log2 units)
 
 __device__ __forceinline__ int k_lds_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
@@ -118,6 +120,9 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
 
   const int ntiles = (S + KVB - 1) / KVB;
   ISSUE_TILE(0, 0);
+#if ATT_NST == 3
+  if (ntiles > 1) ISSUE_TILE(1, 1);
+#endif
 
   // transposed-read lane constants: 16-lane group -> (h, dgrp); lane in group i -> (row q4 = i>>2, col part = i&3)
   const int i16 = lane & 15;
@@ -131,9 +136,19 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
     // tile j has landed (this thread's loads; the barrier publishes everyone's) and every wave is done with tile j-1,
     // whose stage takes tile j+1
 #ifndef ATT_X_NOSYNC      // timing knob (tools/micro/attn_knobs.sh): no DMA stream, no barrier - every tile reads stage 0
+#if ATT_NST == 3
+    // tile j's loads are older than tile j+1's (2 per pass this wave takes part in): those may stay in flight
+    if (j + 1 < ntiles) {
+      if (NPASS == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + 2 < ntiles) ISSUE_TILE(j + 2, (cur + 2) % 3);
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (j + 1 < ntiles) ISSUE_TILE(j + 1, cur ^ 1);
+#endif
 #endif
 #pragma unroll 1
     for (int sub = 0; sub < NSUB; ++sub) {
@@ -269,7 +284,11 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
       }
     }
 #ifndef ATT_X_NOSYNC
+#if ATT_NST == 3
+    cur = cur == 2 ? 0 : cur + 1;
+#else
     cur ^= 1;
+#endif
 #endif
   }
 

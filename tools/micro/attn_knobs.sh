@@ -5,10 +5,10 @@ set -e
 cd "$(dirname "$0")/../../lkgd_amd/csrc"
 make -s
 OBJS=""
-for s in gemm gemm_stream gemm_wide gemm_rowpanel gemm_resw norm attn_temporal attn_tfront attn_cross elementwise fsm conv_small image_ops vae_ops; do OBJS="$OBJS $s.o"; done
+for s in gemm gemm_stream gemm_wide gemm_rowpanel gemm_resw norm attn_temporal attn_tfront attn_cross attn_dense elementwise fsm conv_small image_ops vae_ops; do OBJS="$OBJS $s.o"; done
 rm -f ../../tools/micro/libatt_*.so
 for knob in "$@"; do
-  flags=""; for k in ${knob//+/ }; do case $k in KVB*) flags="$flags -DATT_KVB16=${k#KVB}";; *) flags="$flags -DATT_X_$k";; esac; done
+  flags=""; for k in ${knob//+/ }; do case $k in KVB*) flags="$flags -DATT_KVB16=${k#KVB}";; NST*) flags="$flags -DATT_NST=${k#NST}";; *) flags="$flags -DATT_X_$k";; esac; done
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm $flags -c attn_spatial.hip -o /tmp/attn_$knob.o
   hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/attn_$knob.o -o ../../tools/micro/libatt_$knob.so
 done

@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../../lkgd_amd/csrc"
 make -s
 OBJS=""
-for s in gemm gemm_stream gemm_wide gemm_rowpanel norm attn_spatial attn_temporal attn_cross elementwise fsm conv_small image_ops vae_ops; do OBJS="$OBJS $s.o"; done
+for s in gemm gemm_stream gemm_wide gemm_rowpanel norm attn_spatial attn_temporal attn_tfront attn_cross attn_dense elementwise fsm conv_small image_ops vae_ops; do OBJS="$OBJS $s.o"; done
 KERNEL=gemm_resw
 for knob in BASE "$@"; do
   tag=${knob//=/}; tag=${tag//+/_}
