@@ -67,7 +67,7 @@
 #else
 #define WIDE_MM(X) X
 #endif
-#ifdef WIDE_X_NOBAR
+#if defined(WIDE_X_NOBAR) || defined(WIDE_X_STAMPS)      /* STAMPS: the barrier is issued (and timed) from C++ */
 #define WIDE_BAR(X) ""
 #else
 #define WIDE_BAR(X) X
@@ -268,6 +268,9 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
 
   int cur = 0, kt = 0, tile = tile_begin;
   bool skip_wait = false;
+#ifdef WIDE_X_STAMPS       /* diagnostic build (tools/micro/wide_stamps.py): s_memtime sums per wave, written over the first output rows */
+  long long st_sync = 0, st_body = 0, st_epi = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+#endif
 #ifdef WIDE_X_LATEWAIT     /* timing knob (results wrong): the second body after an epilogue leaves its stores in flight */
   int late = 0;
 #endif
@@ -279,8 +282,15 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
     if (late == 1) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); skip_wait = true; }
     late = skip_wait && late == 0 ? 1 : 0;
 #endif
+#ifdef WIDE_X_STAMPS
+    st_a = __builtin_amdgcn_s_memtime();
+#endif
     if (!skip_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     skip_wait = false;
+#ifdef WIDE_X_STAMPS
+    __builtin_amdgcn_s_barrier();
+    st_b = __builtin_amdgcn_s_memtime(); st_sync += st_b - st_a;
+#endif
     const int m_a = (cur ^ 1) * WSTAGE_BYTES + w * 1024;
     half8_t x1[4], w0;
     if (kt == 0) wide_ktile_a<true>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
@@ -293,6 +303,9 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
       xa0 += d; xa1 += d; wa0 += d; wa1 += d;
     }
     cur ^= 1;
+#ifdef WIDE_X_STAMPS
+    st_a = __builtin_amdgcn_s_memtime(); st_body += st_a - st_b;
+#endif
 
     if (++kt == nk) {
       // ---------------------------------------------------------------- epilogue of `tile`, straight from registers.
@@ -472,9 +485,18 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
           *(float2v*)(p.colstats + ((long long)tm * (p.N / 2) + tn * (WBN / 2) + t) * 2) = (float2v){a, b};
         }
       }
+#ifdef WIDE_X_STAMPS
+      st_epi += __builtin_amdgcn_s_memtime() - st_a;
+#endif
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's trailing loads must land before the LDS is released
+#ifdef WIDE_X_STAMPS
+  if (lane == 0) {
+    long long* dbg = (long long*)p.out + ((long long)blockIdx.x * 8 + w) * 4;
+    dbg[0] = st_sync; dbg[1] = st_body; dbg[2] = st_epi; dbg[3] = __builtin_amdgcn_s_memtime() - st_t0;
+  }
+#endif
 }
 
 template <int MODE, bool LDSOUT>
