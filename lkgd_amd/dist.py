@@ -10,9 +10,13 @@ BASELINE.json's north_star names and SURVEY.md 8e details:
   - temporal GroupNorm: all-reduce of the [32,2] fp32 partial sums (not the activations),
   - temporal Conv3d (3,1,1): needs one frame of halo on each side only - an equal-count all-gather of every rank's two
     BOUNDARY frames (2 of its 3-7 frames; no padding needed) fills the halo slots of a [f_local + 2] frame buffer,
-  - temporal attention: all-gather of the normalised hidden states of the frame slices (C channels, padded to equal
-    size because RCCL's all-gather wants equal counts); K|V for all frames are then projected locally (a 2C x C GEMM
-    on F*HW rows is microseconds; gathering K|V themselves would move twice the bytes).
+  - temporal attention (default since round 3, SURVEY.md 8e variant iii): the tokens are RE-SHARDED by pixels around the
+    attention - an all-to-all turns [f_local, HW, C] into [F, HW/k, C] (all frames of a pixel slice), LayerNorm + Q|K|V +
+    attention run there exactly once per token (the fused lkgd_tattn_front where it applies), a second all-to-all brings the
+    attention output back to frame slices.  A rank sends and receives 2 x (k-1)/k of its slice per block instead of receiving
+    (k-1) slices, and projects no foreign frames.  LKGD_TEMPORAL_GATHER=1 selects the earlier form: all-gather of the
+    normalised hidden states of the frame slices (C channels, padded to equal size because RCCL's all-gather wants equal
+    counts), K|V for all frames projected locally.
   Per forward a rank of 8 receives 1.2 GB this way (2.2 GB with whole-slice gathers before every temporal op), a rank
   of 4 0.6 GB (1.5 GB) - SURVEY.md 8e lists the message sizes.
 
@@ -136,6 +140,89 @@ def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Ten
         for dst, src in pairs:
             dst.copy_(src)
     _step(compact)
+    return out
+
+
+#: temporal attention of a frame-sharded rank: True = all-gather of the normalised hidden states (round 1-2 form),
+#: False = all-to-all re-sharding by pixels around the attention (default)
+TEMPORAL_GATHER = __import__("os").environ.get("LKGD_TEMPORAL_GATHER", "0") == "1"
+
+
+def pixel_splits(HW: int, shards: int) -> Tuple[int, ...]:
+    """contiguous pixel ranges per shard, as even as possible, in units of 16 pixels where HW allows (the fused temporal
+    front works on panels of 16 pixels): 9216 over 4 -> 2304 each; 144 over 4 -> (48, 32, 32, 32)"""
+    unit = 16 if HW % 16 == 0 and HW // 16 >= shards else 1
+    q, r = divmod(HW // unit, shards)
+    if q == 0:
+        raise ValueError(f"cannot split {HW} pixels over {shards} shards")
+    return tuple((q + 1 if i < r else q) * unit for i in range(shards))
+
+
+def all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_rows: List[int], in_rows: List[int], group=None) -> None:
+    """dist.all_to_all_single over dim 0 with per-peer row counts; gloo with device tensors is staged through host memory"""
+    if _backend(group) == "nccl" or not inp.is_cuda:
+        dist.all_to_all_single(out, inp, out_rows, in_rows, group=group)
+        return
+    ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+    dist.all_to_all_single(ho, hi, out_rows, in_rows, group=group)
+    out.copy_(ho)
+
+
+def frames_to_pixels(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+    """local [f_local, HW, C] (this rank's frames, all pixels) -> [F, px_local, C] (all frames, this rank's pixel slice)
+    over the frame group.  Peer r gets this rank's frames of ITS pixel range and sends its frames of ours; the received
+    blocks arrive in rank = frame order, so the result is frame-major without a compaction."""
+    k, si = plan.frame_shards, plan.shard_index
+    if k == 1:
+        return local
+    fl, HW, C = local.shape
+    if fl != plan.f_local or not local.is_contiguous():
+        raise ValueError("frames_to_pixels needs this rank's contiguous [f_local, HW, C] slice")
+    px = pixel_splits(HW, k)
+    p0 = [sum(px[:r]) for r in range(k)]
+    send = torch.empty(fl * HW, C, dtype=local.dtype, device=local.device)
+    recv = torch.empty(plan.num_frames * px[si], C, dtype=local.dtype, device=local.device)
+    in_rows = [fl * px[r] for r in range(k)]
+    out_rows = [plan.splits[r] * px[si] for r in range(k)]
+    pieces, o = [], 0
+    for r in range(k):
+        pieces.append((send[o:o + in_rows[r]].view(fl, px[r], C), local[:, p0[r]:p0[r] + px[r], :]))
+        o += in_rows[r]
+
+    def step():
+        for dst, src in pieces:
+            dst.copy_(src)
+        all_to_all_rows(recv, send, out_rows, in_rows, group)
+    _step(step)
+    return recv.view(plan.num_frames, px[si], C)
+
+
+def pixels_to_frames(x: torch.Tensor, plan: ShardPlan, HW: int, group=None) -> torch.Tensor:
+    """inverse of frames_to_pixels: x [F, px_local, C] -> [f_local, HW, C]"""
+    k, si = plan.frame_shards, plan.shard_index
+    if k == 1:
+        return x
+    F, pl, C = x.shape
+    px = pixel_splits(HW, k)
+    if F != plan.num_frames or pl != px[si] or not x.is_contiguous():
+        raise ValueError("pixels_to_frames needs the contiguous [F, px_local, C] slice frames_to_pixels produced")
+    fl = plan.f_local
+    p0 = [sum(px[:r]) for r in range(k)]
+    recv = torch.empty(fl * HW, C, dtype=x.dtype, device=x.device)
+    out = torch.empty(fl, HW, C, dtype=x.dtype, device=x.device)
+    in_rows = [plan.splits[r] * pl for r in range(k)]          # frames of shard r are contiguous rows of x
+    out_rows = [fl * px[r] for r in range(k)]
+    pieces, o = [], 0
+    for r in range(k):
+        pieces.append((out[:, p0[r]:p0[r] + px[r], :], recv[o:o + out_rows[r]].view(fl, px[r], C)))
+        o += out_rows[r]
+    flat = x.view(F * pl, C)
+
+    def step():
+        all_to_all_rows(recv, flat, out_rows, in_rows, group)
+        for dst, src in pieces:
+            dst.copy_(src)
+    _step(step)
     return out
 
 

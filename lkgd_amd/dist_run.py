@@ -3,7 +3,8 @@
 Exchange points per UNet forward on a rank (frame_shards > 1 only):
   * each temporal GroupNorm  : all-reduce of [1,32,2] fp32 sums                            (22 blocks x 2)
   * each temporal Conv3d     : neighbour send/recv of the two boundary frames [HW,C] each   (22 blocks x 2)
-  * each temporal attention  : all-gather of the normalised hidden states [F,HW,C]; K|V projected locally (16 blocks)
+  * each temporal attention  : all-to-all re-sharding [f_local,HW,C] -> [F,HW/k,C] around the attention and back (16 blocks;
+                               LKGD_TEMPORAL_GATHER=1: all-gather of the normalised hidden states, K|V projected locally)
 and once per step, over ALL ranks, the all-gather of the noise prediction [cfg*F*HW, 4] (1 MB) before the replicated
 CFG-combine + Euler update.  With 2 GPUs (pure CFG-parallel) only the last exchange exists.
 
@@ -23,7 +24,8 @@ import torch.distributed as dist
 
 from . import ops, replay
 from ._lib import LkgdHipError
-from .dist import ShardPlan, all_gather_into, allreduce_sums, exchange_halo, gather_frames, make_plan
+from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, frames_to_pixels, gather_frames, make_plan,
+                   pixels_to_frames)
 
 
 class ShardInfo:
@@ -43,6 +45,17 @@ class ShardInfo:
         x = local.reshape(fl, -1, local.shape[-1])
         full = gather_frames(x, self.plan, self.group)
         return full.reshape(-1, local.shape[-1])
+
+    def to_pixels(self, local: torch.Tensor, HW: int) -> torch.Tensor:
+        """[f_local*HW, C] tokens (own frames, all pixels) -> [F*px_local, C] (all frames, own pixel slice): all-to-all"""
+        x = frames_to_pixels(local.reshape(self.plan.f_local, HW, local.shape[-1]), self.plan, self.group)
+        return x.reshape(-1, local.shape[-1])
+
+    def to_frames(self, x: torch.Tensor, HW: int) -> torch.Tensor:
+        """inverse of to_pixels"""
+        F = self.plan.num_frames
+        out = pixels_to_frames(x.reshape(F, x.shape[0] // F, x.shape[-1]), self.plan, HW, self.group)
+        return out.reshape(-1, x.shape[-1])
 
     def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
         return allreduce_sums(sums, self.plan, self.group)

@@ -527,7 +527,11 @@ class TemporalBasicTransformerBlock(nn.Module):
         # branch reads the normalised tokens again, masked LoRA runs per-entry weights, a sharded rank gathers frames: unfused
         fused = (ctx.lora is None and not ctx.frames_sharded and ops.tattn_front_ok(Cc, self.attn1.heads, ctx.F, ctx.HW) and
                  not (self.enable_joint_attention and hasattr(self, "attn1n")))
-        ln1 = None if fused else ops.layernorm(m1, None, None, 1e-5)
+        from . import dist as _dist
+        # (a level with fewer pixels than shards - the 1x1 level of the tiny test nets - keeps the gathered form)
+        resharded = (ctx.frames_sharded and ctx.lora is None and not _dist.TEMPORAL_GATHER and
+                     ctx.HW >= ctx.shard.plan.frame_shards)
+        ln1 = None if (fused or resharded) else ops.layernorm(m1, None, None, 1e-5)
         if fused:
             if getattr(pk.a1, "wfront", None) is None:
                 from .packing import pack_tfront
@@ -546,8 +550,27 @@ class TemporalBasicTransformerBlock(nn.Module):
             ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
             ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
                               self.attn1.heads)
+        elif resharded:
+            # frames of the clip live on several GPUs: re-shard by PIXELS around the attention (all-to-all), so that this rank
+            # holds all F frames of its pixel slice - LayerNorm, Q|K|V and the attention then run once per token, fused where
+            # the kernel applies - and bring the attention output back to frame slices (lkgd_amd/dist.py)
+            m1p = ctx.shard.to_pixels(m1, ctx.HW)
+            Tp, Ft = m1p.shape[0], ctx.F_total
+            pxl = Tp // Ft
+            attp = ctx.new(Tp, Cc)
+            if ops.tattn_front_ok(Cc, self.attn1.heads, Ft, pxl):
+                if getattr(pk.a1, "wfront", None) is None:
+                    from .packing import pack_tfront
+                    pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
+                ops.tattn_front(m1p, pk.a1.wfront, pk.a1.bqkv, attp, 1, Ft, pxl, self.attn1.heads)
+            else:
+                ln1p = ops.layernorm(m1p, None, None, 1e-5)
+                qkv = ctx.new(Tp, 3 * Cc)
+                ops.gemm(ln1p, pk.a1.wqkv, qkv, M=Tp, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
+                ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], attp, 1, Ft, pxl, self.attn1.heads)
+            att = ctx.shard.to_frames(attp, ctx.HW)
         else:
-            # frames of the clip live on several GPUs: local queries against the keys / values of ALL frames.  The
+            # LKGD_TEMPORAL_GATHER=1: local queries against the keys / values of ALL frames.  The
             # normalised hidden states are gathered (C channels) and K|V projected here for every frame: half the
             # bytes of gathering K|V, for a 2C x C GEMM on F*HW rows
             ln1f = ctx.shard.gather(ln1)

@@ -81,6 +81,25 @@ def _worker(rank, world, port, frames, q):
             want = 3.0 * padded[plan.f0:plan.f0 + plan.f_local + 2]
             ok = ok and torch.equal(hb2, want)
         ld._HALO_ALLGATHER = True
+        # pixel re-sharding around the temporal attention (SURVEY.md 8e variant iii): [f_local, HW, C] -> [F, HW/k, C] and back
+        from lkgd_amd.dist import frames_to_pixels, pixel_splits, pixels_to_frames
+        for HW in (32, 7, 48):
+            if HW < world:
+                continue
+            fullp = torch.arange(frames * HW * 3, dtype=torch.float32).reshape(frames, HW, 3) * 0.5 - 7.0
+            mine = fullp[plan.f0:plan.f0 + plan.f_local].clone()
+            px = pixel_splits(HW, world)
+            ok = ok and sum(px) == HW and all(p > 0 for p in px)
+            p0 = sum(px[:plan.shard_index])
+            with _rp.record() as rec_p:
+                xp = frames_to_pixels(mine, plan)
+                back = pixels_to_frames(xp, plan, HW)
+            ok = ok and torch.equal(xp, fullp[:, p0:p0 + px[plan.shard_index]])
+            ok = ok and torch.equal(back, mine)
+            mine.mul_(-2.0)                      # replay on new values in the same buffers
+            rec_p.run()
+            ok = ok and torch.equal(xp, -2.0 * fullp[:, p0:p0 + px[plan.shard_index]]) and torch.equal(back, mine)
+        ok = ok and pixel_splits(9216, 4) == (2304, 2304, 2304, 2304) and pixel_splits(144, 4) == (48, 32, 32, 32)
         # recorded exchange steps (lkgd_amd/replay.py): new values in the same buffers, same plan
         from lkgd_amd import replay
         src = local.clone()

@@ -203,8 +203,13 @@ def test_sharded_dit_loop_equals_single_process(world):
         assert rel <= 8e-3, f"rank {r['rank']}: sharded DiT loop vs single process: relative L2 {rel:.3e}"
 
 
-@pytest.mark.parametrize("world,frames,guidance_on", [(2, 4, True), (4, 5, True), (2, 5, False), (4, 6, False)])
-def test_sharded_loop_equals_single_process(world, frames, guidance_on):
+@pytest.mark.parametrize("world,frames,guidance_on,gather", [(2, 4, True, False), (4, 5, True, False), (2, 5, False, False),
+                                                             (4, 6, False, False), (4, 6, False, True), (4, 5, True, True)])
+def test_sharded_loop_equals_single_process(world, frames, guidance_on, gather, monkeypatch):
+    """gather = False: the temporal attention re-shards by pixels (all-to-all, the default; the 1x1 level of this tiny net has
+    fewer pixels than shards and keeps the gathered form); True: LKGD_TEMPORAL_GATHER=1, all-gather of the hidden states"""
+    if gather:
+        monkeypatch.setenv("LKGD_TEMPORAL_GATHER", "1")      # read by lkgd_amd.dist at import in the spawned ranks
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
