@@ -103,6 +103,15 @@ typedef struct lkgd_gemm_desc {
                               this GEMM writes, taken while its rows pass through LDS (section 2: lkgd_groupnorm_stats_cols),
                               so the separate statistics pass over the tensor disappears.  blk = lkgd_gemm_colstats_block(d)
                               (256 or 32); must be NULL when that returns 0.  Deterministic (fixed-order sums, no atomics). */
+  const float* ln_colsum;  /* optional fp32 [N]: LayerNorm of the A rows folded into this GEMM (SURVEY K8;
+                              F.layer_norm in front of a Linear, patch/patch.py:416,600): a0 holds the UN-normalised rows, w
+                              the weights with the LayerNorm's gamma folded in (bias its beta), ln_colsum[n] = sum_k w[n][k]; the
+                              kernel takes every row's mean / rstd over its K values from the registers that hold the row and
+                              applies  out = rstd * (acc - mean * ln_colsum[n]) + bias[n] ...  in the epilogue - the normalised
+                              tensor is never written.  Plain A, K = the LayerNorm's width <= 320 (K % 64 == 0), no GEGLU:
+                              the row-panel program; LKGD_E_SHAPE otherwise. */
+  float ln_eps;            /* the LayerNorm's epsilon (with ln_colsum) */
+  int32_t ln_pad_;         /* keeps the struct size a multiple of 8 */
 } lkgd_gemm_desc;
 
 int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream);

@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("geglu", C.c_int32), ("pad_off", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("colstats", C.c_void_p),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_pad_", C.c_int32),
     ]
 
 

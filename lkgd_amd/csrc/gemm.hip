@@ -451,6 +451,10 @@ static int gemm_pick(const lkgd_gemm_desc* d, int cus, int* wide_ks_out) {
   // applicability (forced variants fall back the same way)
   if (pick == 6 && !rw_ok) pick = d->geglu == 80 ? 4 : 1;
   if (pick == 5 && !rp_ok) pick = 1;
+  if (d->ln_colsum) {          // LayerNorm fold: only the row-panel program holds whole rows in registers
+    if (!rp_ok || d->geglu || d->K % 64 || !aligned16(d->ln_colsum) || !(d->ln_eps > 0.f)) return LKGD_E_SHAPE;
+    pick = 5;
+  }
   if (pick == 4 && !wide_ok) pick = 3;
   if (pick == 3 && (!stream_ok || d->M <= 256)) pick = (d->K >= 960 && d->M > 256) ? 2 : 1;
   if (d->geglu == 80 && pick != 4 && pick != 6) return LKGD_E_SHAPE;   // 80-wide interleave: 256x320 / resident-weight kernels

@@ -41,7 +41,11 @@ extern __device__ unsigned long long lkgd_gemm_stamps[256 * 8];
 #endif
 
 // NK = K / 64 (1..5).  LDS: RP_NBUF weight tiles of 64 x K fp16 + 8 per-wave transpose scratches of 32 x 144 B.
-template <int NK>
+// LNF: LayerNorm of the token rows folded in (lkgd_gemm_desc.ln_colsum): the rows sit in registers for the whole sweep over N, so
+// their mean / rstd cost one pass of v_dot2 over the fragments per panel, and the epilogue applies
+// rstd * (acc - mean * colsum[n]) before the bias - the normalised rows are never materialised (fp32 arithmetic on exact fp16
+// products: more accurate than rounding the normalised row to fp16 first).
+template <int NK, bool LNF>
 __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd_gemm_desc p, int panels, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = NK * 64;
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd
 
   half8_t xq[NK * 4];
   float16_t acc[2];
+  float ln_mean = 0.f, ln_rstd = 1.f;              // LNF: statistics of this lane's token row
   int tile_in_panel = 0, panel_idx = 0;
   long long m_row = 0;
   // Optional stagger (waves 4-7 run the epilogue of tile s-1 right after the barrier of step s while waves 0-3 stage +
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e];
           if (n < p.N) {
+            if (LNF) v = (v - ln_mean * *(const float4_t*)(p.ln_colsum + n)) * ln_rstd;
             if (p.bias) v += *(const float4_t*)(p.bias + n);
             if (rbp && mrow < p.M) {
               half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + n);
@@ -249,6 +255,25 @@ __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd
     if (s == 0 || tile_in_panel == 0) {
       // queue may hold [tile s][tile s+1][x panel loads]: wait for everything (once per panel)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (LNF && tile_in_panel == 0) {
+        // this lane holds half of its row (k = 16 ks + 8 h ..): sum and sum of squares by v_dot2, the other half one lane away
+        float s1 = 0.f, s2 = 0.f;
+        const half2_t one = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+        for (int ks = 0; ks < NK * 4; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const half2_t u = {xq[ks][2 * e], xq[ks][2 * e + 1]};
+            s1 = __builtin_amdgcn_fdot2(u, one, s1, false);
+            s2 = __builtin_amdgcn_fdot2(u, u, s2, false);
+          }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        ln_mean = s1 * (1.0f / K);
+        float var = s2 * (1.0f / K) - ln_mean * ln_mean;
+        var = var < 0.f ? 0.f : var;
+        ln_rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+      }
     }
     __builtin_amdgcn_s_barrier();
     RSTAMP(q1)
@@ -320,21 +345,32 @@ __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus) {
   const int nk = d->K / 64;
   if (nk < 1 || nk > 5 || d->mode != LKGD_A_PLAIN || d->csplit < d->K) return LKGD_E_SHAPE;
+  if (d->ln_colsum && (d->geglu || d->K != nk * 64)) return LKGD_E_SHAPE;
   const int lds = RP_NBUF * RP_BN * d->K * 2 + 8 * 4608;
   LKGD_DEVICE_ONCE_BEGIN
     const int mx = RP_NBUF * RP_BN * 320 * 2 + 8 * 4608;
-    if (hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+#define RP_ATTR(NKV, L) (hipFuncSetAttribute((const void*)lkgd_gemm_rowpanel_kernel<NKV, L>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+    if (RP_ATTR(1, false) || RP_ATTR(2, false) || RP_ATTR(3, false) || RP_ATTR(4, false) || RP_ATTR(5, false) ||
+        RP_ATTR(3, true) || RP_ATTR(4, true) || RP_ATTR(5, true))
       return LKGD_E_LAUNCH;
+#undef RP_ATTR
   LKGD_DEVICE_ONCE_END
   const int panels = (d->M + RP_ROWS - 1) / RP_ROWS;
   const int tiles_n = (d->N + RP_BN - 1) / RP_BN;
   const int grid = panels < cus ? panels : cus;
 #define RP_LAUNCH(NKV)                                                                                       \
-  hipLaunchKernelGGL(lkgd_gemm_rowpanel_kernel<NKV>, dim3(grid), dim3(RP_NT), lds, stream, *d, panels, tiles_n)
+  hipLaunchKernelGGL((lkgd_gemm_rowpanel_kernel<NKV, false>), dim3(grid), dim3(RP_NT), lds, stream, *d, panels, tiles_n)
+#define RP_LAUNCH_LN(NKV)                                                                                    \
+  hipLaunchKernelGGL((lkgd_gemm_rowpanel_kernel<NKV, true>), dim3(grid), dim3(RP_NT), lds, stream, *d, panels, tiles_n)
+  if (d->ln_colsum) {
+    switch (nk) {       // the LayerNorm widths of the model's K <= 320 projections: 192 (tiny configs), 256, 320
+      case 3: RP_LAUNCH_LN(3); break;
+      case 4: RP_LAUNCH_LN(4); break;
+      case 5: RP_LAUNCH_LN(5); break;
+      default: return LKGD_E_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+  }
   switch (nk) {
     case 1: RP_LAUNCH(1); break;
     case 2: RP_LAUNCH(2); break;
@@ -343,5 +379,6 @@ extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t st
     default: RP_LAUNCH(5); break;
   }
 #undef RP_LAUNCH
+#undef RP_LAUNCH_LN
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }

@@ -92,7 +92,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
          tconv: Optional[Tuple[int, int]] = None, rowbias: Optional[torch.Tensor] = None,
          rowmap: Optional[RowMap] = None, res1: Optional[torch.Tensor] = None, r1: float = 1.0,
          res2: Optional[torch.Tensor] = None, r2: float = 1.0, s_acc: float = 1.0, geglu: int = 0,
-         colstats: int = 0) -> torch.Tensor:
+         colstats: int = 0, ln: Optional[Tuple[torch.Tensor, float]] = None) -> torch.Tensor:
     """out = epilogue(A(.) @ w.T) - see include/lkgd_hip.h section 1.  ``conv`` = (Hout, Wout, Hin, Win, stride, ups);
     ``tconv`` = (F, HW).  ``colstats`` = rows per GroupNorm sample (0 = off): ``out`` feeds a GroupNorm next - where the
     tile program that will run supports it and its row blocks tile the samples, the GEMM leaves the per-(row block, channel
@@ -135,6 +135,9 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     if M < 12288:               # few-row problems may cut K into slices (lkgd_hip.h: lkgd_gemm_desc.workspace)
         ws = splitk_workspace(out.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if ln is not None:           # LayerNorm of the A rows folded into the GEMM (lkgd_gemm_desc.ln_colsum)
+        _req(ln[0], torch.float32, "ln colsum")
+        d.ln_colsum, d.ln_eps = ln[0].data_ptr(), float(ln[1])
     if colstats and COLSTATS and out.shape[0] == M and out.shape[1] == N:
         blk = _L().lkgd_gemm_colstats_block(C.byref(d))
         if blk > 0 and int(colstats) % blk == 0:
@@ -314,6 +317,15 @@ def attn_cross(q, k, v, out, heads: int, ncontexts: int, Lk: int, rowmap: RowMap
     check(_L().lkgd_attn_cross(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(), _ld(out),
                                q.shape[0], heads, ncontexts, Lk, d1, m1, d2, md, c0, scale, _stream()), "lkgd_attn_cross")
     return out
+
+
+#: A/B switch of the LayerNorm fold into the row-panel QKV projection (False = LayerNorm kernel + GEMM)
+LNFOLD = os.environ.get("LKGD_NO_LNFOLD", "0") != "1"
+
+
+def gemm_ln_ok(M: int, N: int, K: int) -> bool:
+    """shapes for which gemm(..., ln=...) runs (the row-panel program) AND pays: K = LayerNorm width <= 320, many rows"""
+    return LNFOLD and K <= 320 and K % 64 == 0 and K >= 192 and M >= 32768 and N % 8 == 0
 
 
 def attn_dense(q, k, v, out, nbatch: int, S: int, heads: int, head_dim: int, scale: Optional[float] = None):

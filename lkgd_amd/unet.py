@@ -187,7 +187,10 @@ class Attention(nn.Module):
         if norm is not None:
             w, bqkv = _fold_ln(norm, w, None)
             bqkv = bqkv.contiguous()
-        return SimpleNamespace(wqkv=pack_linear(w), bqkv=bqkv,
+        wq = pack_linear(w)
+        # column sums of the PACKED (fp16) weights: what the LayerNorm fold of ops.gemm(ln=...) subtracts, times the row mean
+        cs = wq.float().sum(dim=1).contiguous() if norm is not None else None
+        return SimpleNamespace(wqkv=wq, bqkv=bqkv, cs=cs,
                                wo=pack_linear(_eff_weight(self.to_out[0], ao)), bo=_f32(self.to_out[0].bias))
 
     def pack_cross(self, norm: nn.LayerNorm):
@@ -380,9 +383,15 @@ class BasicTransformerBlock(nn.Module):
     def run(self, ctx: Ctx, h: torch.Tensor) -> torch.Tensor:
         pk, T, Cc = self._pk, h.shape[0], h.shape[1]
         heads = self.attn1.heads
-        ln = ops.layernorm(h, None, None, 1e-5)
+        # norm1 folded into the QKV projection where the row-panel program runs it (K = 320 at many rows): the normalised
+        # tokens are never written; the joint branch reads them again and keeps the LayerNorm pass
+        fold = (ctx.lora is None and pk.a1.cs is not None and ops.gemm_ln_ok(T, 3 * Cc, Cc) and
+                not (self.enable_joint_attention and hasattr(self, "attn1n")))
+        ln = None if fold else ops.layernorm(h, None, None, 1e-5)
         qkv = ctx.new(T, 3 * Cc)
-        if ctx.lora is None:
+        if fold:
+            ops.gemm(h, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv, ln=(pk.a1.cs, 1e-5))
+        elif ctx.lora is None:
             ops.gemm(ln, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
         else:
             va = [_attn_variant(self, "a1", ctx, i, True) for i in range(len(ctx.lora.runs))]

@@ -22,7 +22,8 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), s
     assert lib.lkgd_version().decode().startswith("lkgd_hip")
-    assert ctypes.sizeof(_lib.GemmDesc) == 9 * 8 + 31 * 4 + 4 + 16 + 8   # 31 int32/float fields, padded to 8; workspace + size; colstats
+    # 31 int32/float fields, padded to 8; workspace + size; colstats; ln_colsum + ln_eps + pad
+    assert ctypes.sizeof(_lib.GemmDesc) == 9 * 8 + 31 * 4 + 4 + 16 + 8 + 16
 
 
 def test_gemm_desc_validation_without_gpu():

@@ -843,3 +843,41 @@ def test_temporal_attention_front_fused(B, Fr, HW):
     att = torch.empty(T, C, dtype=torch.float16, device=DEV)
     ops.attn_temporal(qkv_d[:, :C], qkv_d[:, C:2 * C], qkv_d[:, 2 * C:], att, B, Fr, HW, heads)
     assert ((out.float() - att.float()).norm() / att.float().norm()).item() < 3e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,res", [(40000, 960, 320, False), (33000, 320, 320, True), (36864, 576, 192, False), (4100, 768, 256, False)])
+def test_gemm_layernorm_fold(M, N, K, res):
+    """lkgd_gemm_desc.ln_colsum: LayerNorm of the A rows folded into the row-panel GEMM (patch/patch.py:416 norm1 -> to_q/k/v) vs
+    fp32 layer_norm -> linear, and vs the two-launch HIP form; rows with |mean| >> sigma included"""
+    from lkgd_amd import ops
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device=DEV) * 1.3
+    x[::7] += 6.0                                     # large row means: the fold subtracts mean * colsum in fp32
+    x[5::11] *= 0.05
+    x = x.half()
+    gamma, beta = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.2
+    w = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV) * 0.1
+    wf = (w * gamma[None, :]).half().contiguous()      # gamma folded into the weights, beta into the bias
+    bf = (b + w @ beta).contiguous()
+    cs = wf.float().sum(dim=1).contiguous()
+    r = (torch.randn(M, N, device=DEV) * 0.5).half() if res else None
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(x, wf, out, M=M, N=N, K=K, bias=bf, res1=r, ln=(cs, 1e-5))
+    want = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + b
+    if res:
+        want = want + r.float()
+    err = (out.float() - want).abs().max().item()
+    rel = ((out.float() - want).norm() / want.norm()).item()
+    assert rel < 2e-3 and err < 3e-2, (rel, err)
+    two = torch.empty_like(out)
+    ops.gemm(ops.layernorm(x, None, None, 1e-5), wf, two, M=M, N=N, K=K, bias=bf, res1=r)
+    rel2 = ((out.float() - two.float()).norm() / two.float().norm()).item()
+    assert rel2 < 2e-3, rel2
+    # shapes outside the row-panel program are refused, not silently run without the LayerNorm
+    from lkgd_amd._lib import LkgdHipError
+    xw = torch.zeros(4096, 640, dtype=torch.float16, device=DEV)
+    with pytest.raises(LkgdHipError):
+        ops.gemm(xw, torch.zeros(640, 640, dtype=torch.float16, device=DEV), torch.empty(4096, 640, dtype=torch.float16, device=DEV),
+                 M=4096, N=640, K=640, ln=(torch.zeros(640, device=DEV), 1e-5))
