@@ -107,6 +107,7 @@ __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd
   half8_t xq[NK * 4];
   float16_t acc[2];
   float ln_mean = 0.f, ln_rstd = 1.f;              // LNF: statistics of this lane's token row
+  float4_t ln_cs[8];                               // LNF: column sums of the current weight tile (this lane's 8 channel quads)
   int tile_in_panel = 0, panel_idx = 0;
   long long m_row = 0;
   // Optional stagger (waves 4-7 run the epilogue of tile s-1 right after the barrier of step s while waves 0-3 stage +
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e];
           if (n < p.N) {
-            if (LNF) v = (v - ln_mean * *(const float4_t*)(p.ln_colsum + n)) * ln_rstd;
+            if (LNF) v = (v - ln_mean * ln_cs[i * 4 + g]) * ln_rstd;
             if (p.bias) v += *(const float4_t*)(p.bias + n);
             if (rbp && mrow < p.M) {
               half4_t rb = *(const half4_t*)(rbp + idx * p.ldrb + n);
@@ -277,6 +278,19 @@ __global__ __launch_bounds__(RP_NT, 2) void lkgd_gemm_rowpanel_kernel(const lkgd
     }
     __builtin_amdgcn_s_barrier();
     RSTAMP(q1)
+    if (LNF) {
+      // this tile's column sums, issued BEFORE the next ring stage so that the counted ring wait below retires them with tile
+      // s+1 (queue: [tile s+1][these][tile s+2]) and the epilogue finds them in registers instead of waiting for L2
+      const int n0 = tile_in_panel * RP_BN;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + i * 32 + 8 * g + 4 * h;
+          ln_cs[i * 4 + g] = n < p.N ? *(const float4_t*)(p.ln_colsum + n) : (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+      asm volatile("" ::: "memory");
+    }
     if (s + 2 < total) stage();
     if (late) {
       // late group: its ring wait for tile s+1 sits here, where its queue is [tile s+1][epilogue s-2][tile s+2]
