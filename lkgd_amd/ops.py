@@ -324,8 +324,9 @@ LNFOLD = os.environ.get("LKGD_NO_LNFOLD", "0") != "1"
 
 
 def gemm_ln_ok(M: int, N: int, K: int) -> bool:
-    """shapes for which gemm(..., ln=...) runs (the row-panel program) AND pays: K = LayerNorm width <= 320, many rows"""
-    return LNFOLD and K <= 320 and K % 64 == 0 and K >= 192 and M >= 32768 and N % 8 == 0
+    """shapes for which gemm(..., ln=...) runs (the row-panel program) AND pays: K = LayerNorm width <= 320 and enough 256-row
+    panels to fill the CUs (a rank of 8 has 144 at the 72x128 level: LayerNorm + 256x320 tiles stay ahead there)"""
+    return LNFOLD and K <= 320 and K % 64 == 0 and K >= 192 and M >= 60000 and N % 8 == 0
 
 
 def attn_dense(q, k, v, out, nbatch: int, S: int, heads: int, head_dim: int, scale: Optional[float] = None):
