@@ -13,6 +13,11 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#ifdef QUAD_X_VLOAD           /* timing knob: the same bytes fetched into a (dead) register instead of LDS: is it the LDS write side? */
+#define QUAD_LD(X, Y) Y
+#else
+#define QUAD_LD(X, Y) X
+#endif
 #include "gemm_quad_body.inc"
 
 typedef _Float16 half_t;
@@ -50,9 +55,11 @@ __device__ __forceinline__ void q_body(half8_t (&xn)[4], half8_t& w0n, const hal
                  "v"(in.vB[0]), "v"(in.vB[1]), "v"(in.vB[2]), "s"(in.sA), "s"(in.sB), "s"(in.m_a)                           \
                : "memory", "scc", QUAD_AGPR_CLOBBERS)
   if (FIRST) {
-    if (LOAD == 3) { QSTMT(QUAD_BODY_FIRST_NB3); } else if (LOAD == 2) { QSTMT(QUAD_BODY_FIRST_NB2); } else { QSTMT(QUAD_BODY_FIRST_NOLOAD); }
+    if (LOAD == 3) { QSTMT(QUAD_BODY_FIRST_NB3_EARLY); } else if (LOAD == 2) { QSTMT(QUAD_BODY_FIRST_NB2); }
+    else if (LOAD == 12) { QSTMT(QUAD_BODY_FIRST_NB2_LATE); } else { QSTMT(QUAD_BODY_FIRST_NOLOAD); }
   } else {
-    if (LOAD == 3) { QSTMT(QUAD_BODY_NEXT_NB3); } else if (LOAD == 2) { QSTMT(QUAD_BODY_NEXT_NB2); } else { QSTMT(QUAD_BODY_NEXT_NOLOAD); }
+    if (LOAD == 3) { QSTMT(QUAD_BODY_NEXT_NB3_EARLY); } else if (LOAD == 2) { QSTMT(QUAD_BODY_NEXT_NB2); }
+    else if (LOAD == 12) { QSTMT(QUAD_BODY_NEXT_NB2_LATE); } else { QSTMT(QUAD_BODY_NEXT_NOLOAD); }
   }
 #undef QSTMT
 }
@@ -80,10 +87,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void g
     auto arow = [&](int g) { int r = tm * 256 + g * 16 + drow; return r < M ? r : M - 1; };
     in.vA[0] = (unsigned)arow(w) * (unsigned)lda * 2u + dch * 16;
     in.vA[1] = (unsigned)arow(w + 8) * (unsigned)lda * 2u + dch * 16;
+#ifdef QUAD_X_WPACK          /* W pre-packed as LDS images [tile column][half tile][20 KiB]: every LDS-DMA instruction reads 1 KiB contiguous */
+    in.vB[0] = (unsigned)(w * 1024 + lane * 16);
+    in.vB[1] = (unsigned)((w + 8) * 1024 + lane * 16);
+    in.vB[2] = (unsigned)(((three ? w + 16 : w)) * 1024 + lane * 16);
+#else
     auto wrow = [&](int g) { return tn * 320 + g * 16 + drow; };
     in.vB[0] = (unsigned)wrow(w) * (unsigned)ldw * 2u + dch * 16;
     in.vB[1] = (unsigned)wrow(w + 8) * (unsigned)ldw * 2u + dch * 16;
     in.vB[2] = (unsigned)wrow(three ? w + 16 : w) * (unsigned)ldw * 2u + dch * 16;
+#endif
   }
   // ---- fragment read addresses (stage 0): lane (l15, lq) reads row l15 of the fragment, position chunk lq ^ (((l15 >> 3) & 1) << 1)
   const int lane_sw = l15 * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) << 4);
@@ -92,7 +105,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void g
   // ---- prologue: half tiles 0, 1, 2 by plain issue
   auto issue = [&](int s) {
     const char* a = (const char*)A + (size_t)s * 64;
+#ifdef QUAD_X_WPACK
+    const char* b = (const char*)W + ((size_t)tn * nh + s) * 20480;
+#else
     const char* b = (const char*)W + (size_t)s * 64;
+#endif
     char* d = smem + stage_of(s) + w * 1024;
     q_glds(a + in.vA[0], d);
     q_glds(a + in.vA[1], d + 8192);
@@ -111,19 +128,35 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void g
   wA = *(const half8_t*)(smem + wa0);
   auto step = [&](int s, auto firstc, half8_t (&xc)[4], half8_t& w0c, half8_t (&xn)[4], half8_t& w0n) {
     constexpr int FIRST = decltype(firstc)::value;
+#ifndef QUAD_X_NOBAR          /* timing knob: no wait, no barrier (results wrong) */
     if (s > 0) {
       // own loads of half tile s+1 landed: only half tile s+2's may still be in flight
+#ifndef QUAD_X_NOWAIT         /* timing knob: the loads are issued but never waited for (results wrong) */
       if (s + 2 < nh) { if (three) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       __builtin_amdgcn_s_barrier();
     }
+#endif
     const int cur = stage_of(s), nxt = stage_of(s + 1);
     in.sA = (const char*)A + (size_t)(s + 3) * 64;
+#ifdef QUAD_X_WPACK
+    in.sB = (const char*)W + ((size_t)tn * nh + (s + 3)) * 20480;
+#else
     in.sB = (const char*)W + (size_t)(s + 3) * 64;
+#endif
     in.m_a = stage_of(s + 3) + w * 1024;
+#ifdef QUAD_X_NODMA           /* timing knob: the K-loop reads whatever the prologue left in LDS */
+    if (false) {
+#else
     if (s + 3 < nh) {
+#endif
       if (three) q_body<FIRST, 3>(xn, w0n, xc, w0c, wa0 + cur, xa0 + nxt, wa0 + nxt, in);
+#ifdef QUAD_X_LATE            /* experiment: waves 4-7 issue their loads in the second half of the body (waves 0-3 in the first) */
+      else q_body<FIRST, 12>(xn, w0n, xc, w0c, wa0 + cur, xa0 + nxt, wa0 + nxt, in);
+#else
       else q_body<FIRST, 2>(xn, w0n, xc, w0c, wa0 + cur, xa0 + nxt, wa0 + nxt, in);
+#endif
     } else {
       q_body<FIRST, 0>(xn, w0n, xc, w0c, wa0 + cur, xa0 + nxt, wa0 + nxt, in);
     }
@@ -163,7 +196,24 @@ int main(int argc, char** argv) {
     for (auto& v : w) v = (half_t)frand(seed);
     half_t *da, *dw, *dc;
     hipMalloc(&da, a.size() * 2); hipMalloc(&dw, w.size() * 2); hipMalloc(&dc, c.size() * 2);
-    hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice);
+#ifdef QUAD_X_WPACK
+    {
+      std::vector<half_t> wp((size_t)N * K);
+      const int nhh = K / 32;
+      for (int tn_ = 0; tn_ < N / 320; ++tn_)
+        for (int kh = 0; kh < nhh; ++kh)
+          for (int r = 0; r < 320; ++r)
+            for (int c = 0; c < 4; ++c) {
+              const int sc = c ^ ((((r & 15) >> 3) & 1) << 1);          // position chunk c of row r holds source chunk sc
+              for (int e = 0; e < 8; ++e)
+                wp[((size_t)tn_ * nhh + kh) * 10240 + r * 32 + c * 8 + e] = w[(size_t)(tn_ * 320 + r) * K + kh * 32 + sc * 8 + e];
+            }
+      hipMemcpy(dw, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+    }
+#else
+    hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice);
+#endif
     hipMemset(dc, 0, c.size() * 2);
     const int tm = (M + 255) / 256, tn = N / 320;
     hipLaunchKernelGGL(gemm_quad_kernel, dim3(tm * tn), dim3(512), 4 * QST, 0, da, K, dw, K, dc, N, M, N, K, tn);
@@ -178,7 +228,9 @@ int main(int argc, char** argv) {
       }
     printf("check M=%d N=%d K=%d: max abs err %.4g (%s)\n", M, N, K, maxerr, maxerr < 2e-2 ? "ok" : "WRONG");
     hipFree(da); hipFree(dw); hipFree(dc);
+#if !defined(QUAD_X_NODMA) && !defined(QUAD_X_NOBAR) && !defined(QUAD_X_NOWAIT) && !defined(QUAD_X_VLOAD)
     if (!(maxerr < 2e-2)) return 1;
+#endif
   }
   // ---- timing: deep K and the model's linear shapes
   const int shapes[][3] = {{32768, 2560, 5120}, {64512, 1920, 640}, {64512, 640, 2560}, {16128, 1280, 5120}, {258048, 320, 1280}, {258048, 960, 320}};
