@@ -376,6 +376,8 @@ const char* lkgd_version(void);
  *      lkgd_debug_set_wide_lds_out(on)  256x320 program: 0 = direct 8-byte stores everywhere, 1 / -1 = rows through LDS where used
  *      lkgd_debug_set_attn_waves(nw)    spatial attention: waves per workgroup (4 / 8 / 16); 0 = by sequence length
  *      lkgd_debug_set_attn_kvb(kvb)     spatial attention: keys per barrier (64 / 128); 0 = default
+ *      lkgd_debug_set_attn_pipe(mode)   spatial attention: 1 = never the software-pipelined program (attn_spatial_pipe.hip),
+ *                                       2 = wherever it is legal (S a multiple of 128); 0 = by sequence length
  *      lkgd_debug_set_gn_apply_kb(kb) / lkgd_debug_set_gn_stats_kb(kb)   GroupNorm chunk sizes in KiB (>= 32)
  * ------------------------------------------------------------------------------------------------------------- */
 void lkgd_debug_set_gemm_variant(int32_t v);
@@ -384,6 +386,7 @@ void lkgd_debug_set_wide_ksplit(int32_t k);
 void lkgd_debug_set_wide_lds_out(int32_t on);
 void lkgd_debug_set_attn_waves(int32_t nw);
 void lkgd_debug_set_attn_kvb(int32_t kvb);
+void lkgd_debug_set_attn_pipe(int32_t mode);
 void lkgd_debug_set_gn_apply_kb(int32_t kb);
 void lkgd_debug_set_gn_stats_kb(int32_t kb);
 

@@ -103,6 +103,7 @@ SYMBOLS = {
     "lkgd_debug_set_wide_lds_out": (None, [_i32]),
     "lkgd_debug_set_attn_waves": (None, [_i32]),
     "lkgd_debug_set_attn_kvb": (None, [_i32]),
+    "lkgd_debug_set_attn_pipe": (None, [_i32]),
     "lkgd_debug_set_gn_apply_kb": (None, [_i32]),
     "lkgd_debug_set_gn_stats_kb": (None, [_i32]),
 }

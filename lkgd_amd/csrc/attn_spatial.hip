@@ -311,8 +311,15 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
 
 static int attn_nw_override = 0;     // A/B knobs: waves per workgroup / keys per stage regardless of S
 static int attn_kvb_override = 0;
+static int attn_pipe_mode = 0;       // 0 = by rule, 1 = never the software-pipelined program, 2 = wherever it is legal
 extern "C" void lkgd_debug_set_attn_waves(int nw) { attn_nw_override = nw; }
 extern "C" void lkgd_debug_set_attn_kvb(int kvb) { attn_kvb_override = kvb; }
+extern "C" void lkgd_debug_set_attn_pipe(int mode) { attn_pipe_mode = mode; }
+
+// attn_spatial_pipe.hip: two query tiles per wave, generated software-pipelined main loop; S % 128 == 0
+int lkgd_attn_pipe_launch(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
+                          int32_t ldo, int32_t nbatch, int32_t Sq, int32_t S, int32_t heads, const int32_t* kv_batch_map,
+                          float scale, hipStream_t stream);
 
 template <int NW, int KVB>
 static int attn_launch(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
@@ -342,6 +349,12 @@ extern "C" int lkgd_attn_spatial_qk(const void* q, int32_t ldq, const void* k, i
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return LKGD_E_ALIGN;
   if (ldq < heads * 64 || ldk < heads * 64 || ldv < heads * 64 || ldo < heads * 64) return LKGD_E_SHAPE;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || ((uintptr_t)out & 7)) return LKGD_E_ALIGN;
+  // the software-pipelined program where a workgroup's 512 queries tile the sequence well and the key loop is long enough
+  // to amortise its prologue (tools/attn_bench.py with ATTN_PIPE = 1 / 2)
+  if (attn_pipe_mode != 1 && S % 128 == 0 && !attn_nw_override && !attn_kvb_override &&
+      (attn_pipe_mode == 2 || (S >= 2048 && Sq >= 2048)))
+    return lkgd_attn_pipe_launch(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, S, heads, kv_batch_map, scale,
+                                 (hipStream_t)stream);
   // queries per workgroup: 512 at S >= 8192, 256 at S >= 2304, else 128 (tools/attn_bench.py with ATTN_WAVES)
   const int nw = attn_nw_override ? attn_nw_override : (Sq >= 8192 ? 16 : Sq >= 2304 ? 8 : 4);
   const int kvb = attn_kvb_override ? attn_kvb_override : (nw == 16 ? ATT_KVB16 : 64);

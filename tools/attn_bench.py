@@ -15,6 +15,9 @@ if os.environ.get("ATTN_WAVES"):        # A/B knob: 4, 8 or 16 waves (128 / 256 
 if os.environ.get("ATTN_KVB"):          # A/B knob: 64 or 128 keys staged per barrier
     from lkgd_amd import _lib
     _lib.lib().lkgd_debug_set_attn_kvb(int(os.environ["ATTN_KVB"]))
+if os.environ.get("ATTN_PIPE"):         # 1 = compiler-scheduled kernel everywhere, 2 = software-pipelined program wherever legal
+    from lkgd_amd import _lib
+    _lib.lib().lkgd_debug_set_attn_pipe(int(os.environ["ATTN_PIPE"]))
 
 
 def bench(fn, iters=5):
