@@ -350,9 +350,10 @@ extern "C" int lkgd_attn_spatial_qk(const void* q, int32_t ldq, const void* k, i
   if (ldq < heads * 64 || ldk < heads * 64 || ldv < heads * 64 || ldo < heads * 64) return LKGD_E_SHAPE;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || ((uintptr_t)out & 7)) return LKGD_E_ALIGN;
   // the software-pipelined program where a workgroup's 512 queries tile the sequence well and the key loop is long enough
-  // to amortise its prologue (tools/attn_bench.py with ATTN_PIPE = 1 / 2)
+  // to amortise its prologue: the 72x128 level (2.74 vs 3.13 ms); at 36x64 (4.5 workgroups per image and head) the two
+  // programs are equal, 0.42 ms (tools/attn_bench.py with ATTN_PIPE = 1 / 2, profiles/r04_attn_pipe_opts.txt)
   if (attn_pipe_mode != 1 && S % 128 == 0 && !attn_nw_override && !attn_kvb_override &&
-      (attn_pipe_mode == 2 || (S >= 2048 && Sq >= 2048)))
+      (attn_pipe_mode == 2 || (S >= 4096 && Sq >= 4096)))
     return lkgd_attn_pipe_launch(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, S, heads, kv_batch_map, scale,
                                  (hipStream_t)stream);
   // queries per workgroup: 512 at S >= 8192, 256 at S >= 2304, else 128 (tools/attn_bench.py with ATTN_WAVES)

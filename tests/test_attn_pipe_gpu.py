@@ -74,17 +74,18 @@ def test_pipe_strided_qkv_layout(L):
     _close(out, _ref(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], nb, heads), "pipe strided")
 
 
-@pytest.mark.parametrize("where", [5, 70, 200, 300, 383])
+@pytest.mark.parametrize("where", [5, 70, 130, 200, 260, 330, 400, 460, 511])
 def test_pipe_reference_moves(L, where):
-    """one key dominates a query late in the sequence (in tile A or B of a wave, in every phase position of a stage): the
-    out-of-line block that moves the reference maximum rescales S, O and l exactly once"""
+    """one key dominates queries of tile A and of tile B of a wave, in every 64-key sub-tile of a four-stage sequence: every
+    instance of the out-of-line block that recomputes a unit (one per phase of the loop body + the tail; the sub-tile one
+    stage behind the fragment addresses included) moves the reference and rescales O and l exactly once"""
     from lkgd_amd import ops
     g = torch.Generator().manual_seed(99 + where)
-    S, C = 384, 64
+    S, C = 512, 64
     q, k, v = (torch.randn(S, C, generator=g) for _ in range(3))
-    k[where] = q[3] * 6.0 + q[40] * 5.0                 # queries of tile A / tile B of different waves
-    k[(where + 77) % S] = q[100] * 7.0
-    k[(where + 130) % S] = q[250] * 4.0
+    k[where] = q[3] * 6.0 + q[40] * 5.0                 # queries of tile A / tile B of wave 0
+    k[(where + 77) % S] = q[100] * 7.0                  # tile B of wave 1
+    k[(where + 130) % S] = q[250] * 4.0 + q[200] * 4.0  # tile B / tile A of wave 3
     q, k, v = q.half().to(DEV), k.half().to(DEV), v.half().to(DEV)
     out = torch.empty(S, C, dtype=torch.float16, device=DEV)
     L.lkgd_debug_set_attn_pipe(2)
@@ -112,10 +113,10 @@ def test_pipe_very_negative_and_very_large_scores(L):
 
 
 def test_pipe_is_deterministic_and_default_at_unet_levels(L):
-    """bitwise repeatable; and the dispatch rule sends the 72x128 / 36x64 shapes to it (same bits as the forced run)"""
+    """bitwise repeatable; and the dispatch rule sends the 72x128-level shape to it (same bits as the forced run)"""
     from lkgd_amd import ops
     g = torch.Generator().manual_seed(11)
-    nb, heads, S = 1, 2, 2304
+    nb, heads, S = 1, 1, 9216
     C = heads * 64
     qkv = torch.randn(nb * S, 3 * C, generator=g).half().to(DEV)
     outs = []

@@ -11,8 +11,11 @@ A wave owns TWO 32-query tiles A, B.  A "unit" u = (tile, 64-key sub-tile); unit
     VALU : softmax(u_n)          32 v_exp_f32 + 32 adds (row sum) + 16 cvt_pk (P -> fp16 B operand) on tile T = n & 1
     MFMA : QK^T(u_{n+1})         2 bias k-steps (A = e0, B = -m: the reference maximum is subtracted by the matrix pipe) + 8
            P.V (u_{n-1})         8                                                     ... both on tile T' = the other tile
-    VALU : max over S(u_{n+1})   16 v_max3, then ONE compare + branch: the reference only moves when a score exceeds it by > 4
-                                 (log2 units); the rare move is an out-of-line block that patches S, O, l, m of tile T'.
+    The reference maximum m of a tile is checked AFTER the exponentials, on the unit's row-sum partial (free: the adds are
+    there anyway; 16 v_max3 per unit in front of the exponentials cost 0.5 ms of 2.9 at S = 9216, profiles/
+    r04_attn_pipe_knobs.txt): while every lane's partial stays <= 1024 no probability exceeds 2^10 (fp16 holds 2^16) and
+    nothing happens.  Otherwise (rare: a score jumped by > ~7 over the reference) an out-of-line block recomputes the unit
+    from LDS - QK^T again, true maximum, new reference, exponentials, sums, conversions - and rescales O and l.
 K / V^T fragments stream through a ring of four 4-register slots, read four MFMAs ahead (counted lgkmcnt).
 Stages of 128 keys (two sub-tiles) live in a three-buffer LDS ring filled by LDS-DMA one stage ahead; ONE barrier per stage.
 
@@ -44,7 +47,8 @@ VB = 24
 S_ = {"A": VB, "B": VB + 32}
 PF = {"A": VB + 64, "B": VB + 80}
 RING = VB + 96
-L_ = {"A": VB + 112, "B": VB + 114}          # two partial row sums per tile (adjacent adds stay independent)
+L_ = {"A": VB + 112, "B": VB + 113}          # running row sums
+PS0, PS1 = VB + 114, VB + 115                 # the current unit's row-sum partials (even / odd scores: adjacent adds independent)
 MB = {"A": VB + 116, "B": VB + 117}
 MX, MX2 = VB + 118, VB + 119                  # two partial tile maxima (one tile at a time is between its max and its compare)
 T0, T1, T2, T3 = VB + 120, VB + 121, VB + 122, VB + 123
@@ -55,11 +59,12 @@ ABIAS = 96
 BB = {"A": 100, "B": 104}
 AEND = 108
 # named SGPRs (clobbered): DMA source pointers, counters
-SK, SV, SIT, SDST, SKPOS, SVPOS, STMP, STMP2, SP1 = 60, 62, 64, 65, 66, 67, 68, 69, 70   # SP1 = s[70:71]
-SEND = 72
+SK, SV, SIT, SDST, SKPOS, SVPOS, STMP, STMP2, SP1, SKD = 60, 62, 64, 65, 66, 67, 68, 69, 70, 72   # SP1 = s[70:71]
+SEND = 73
 STAGE = 32768
 NBUF = 3
-THR = "4.0"          # inline constant
+OPT = os.environ.get("ATTN_GEN_OPT", "w2").split("+")   # schedule options (A/B: tools/micro/attn_pipe_opts.sh)
+PSUM_LIMIT = "0x44800000"   # 1024.0
 
 
 def v(n):
@@ -120,7 +125,7 @@ class Gen:
                    frag=frag, nops=1)
 
     # ---- one phase -----------------------------------------------------------------------------------------------------
-    def phase(self, name, sm, mm, do_qk, do_pv, ksub, vsub, do_max, prefetched, nextfrags):
+    def phase(self, name, sm, mm, do_qk, do_pv, ksub, vsub, prefetched, nextfrags):
         """sm: tile whose softmax runs (or None); mm: tile of the MFMAs; prefetched: the first four fragments are already in
         flight; nextfrags: fragments of the following phase to read behind this phase's last four fragment MFMAs (or None)"""
         self.e("; ---- phase %s: softmax %s | mfma tile %s qk=%d pv=%d" % (name, sm, mm, do_qk, do_pv), "comment")
@@ -144,34 +149,23 @@ class Gen:
         # ---- filler queue
         fill = []
         if sm:
-            s0, p0, l0 = S_[sm], PF[sm], L_[sm]
+            s0, p0 = S_[sm], PF[sm]
+            def E(r):
+                return ("E", "v_exp_f32_e32 %s, %s" % (v(s0 + r), v(s0 + r)), [("v", s0 + r)], [("v", s0 + r)], 8)
+            def C(q):
+                return ("C", "v_cvt_pk_f16_f32 %s, %s, %s" % (v(p0 + q), v(s0 + 2 * q), v(s0 + 2 * q + 1)),
+                        [("v", s0 + 2 * q), ("v", s0 + 2 * q + 1)], [("v", p0 + q)], 4)
             for q in range(16):
+                fill += [E(2 * q), E(2 * q + 1)]
                 for r in (2 * q, 2 * q + 1):
-                    fill.append(("E", "v_exp_f32_e32 %s, %s" % (v(s0 + r), v(s0 + r)), [("v", s0 + r)], [("v", s0 + r)], 8))
-                for r in (2 * q, 2 * q + 1):
-                    la = l0 + (r & 1)
-                    fill.append(("A", "v_add_f32_e32 %s, %s, %s" % (v(la), v(la), v(s0 + r)), [("v", la), ("v", s0 + r)], [("v", la)], 4))
-                fill.append(("C", "v_cvt_pk_f16_f32 %s, %s, %s" % (v(p0 + q), v(s0 + 2 * q), v(s0 + 2 * q + 1)),
-                             [("v", s0 + 2 * q), ("v", s0 + 2 * q + 1)], [("v", p0 + q)], 4))
-        mxq = []
-        if do_max:
-            sb = S_[mm]
-            def m3(d, a, b, c):
-                rd = [("v", x) for x in (a, b, c)]
-                mxq.append(("M", "v_max3_f32 %s, %s, %s, %s" % (v(d), v(a), v(b), v(c)), rd, [("v", d)], 4))
-            ca = [(MX, sb, sb + 1, sb + 2)] + [(MX, MX, sb + r, sb + r + 1) for r in range(3, 15, 2)]
-            cb = [(MX2, sb + 15, sb + 16, sb + 17)] + [(MX2, MX2, sb + r, sb + r + 1) for r in range(18, 30, 2)]
-            for x, y in zip(ca, cb):
-                m3(*x)
-                m3(*y)
-            m3(MX, MX, sb + 30, sb + 31)
-            mxq.append(("M", "v_max_f32_e32 %s, %s, %s" % (v(MX), v(MX), v(MX2)), [("v", MX), ("v", MX2)], [("v", MX)], 4))
-            assert len(mxq) == 16
+                    ps = PS0 + (r & 1)
+                    if q == 0:
+                        fill.append(("A", "v_add_f32_e32 %s, 0, %s" % (v(ps), v(s0 + r)), [("v", s0 + r)], [("v", ps)], 4))
+                    else:
+                        fill.append(("A", "v_add_f32_e32 %s, %s, %s" % (v(ps), v(ps), v(s0 + r)), [("v", ps), ("v", s0 + r)], [("v", ps)], 4))
+                fill.append(C(q))
         ngaps = max(len(mf), 1)
-        last_qk = max([i for i, m in enumerate(mf) if m[0] == "QK"], default=-1)
-        mgap = last_qk + 3                       # first gap in which the maxima may be read (checked again by check())
-        total = sum(x[4] for x in fill) + sum(x[4] for x in mxq)
-        fi = mi = 0
+        fi = 0
         if not prefetched:
             for j in range(min(4, nfr)):
                 self.read_frag(frags[j], j % 4)
@@ -182,7 +176,8 @@ class Gen:
                 if m[1] is not None:
                     slot = frn % 4
                     reg = RING + 4 * slot
-                    self.e("WAITFRAG", "waitfrag", frag=m[1])
+                    if "w2" not in OPT or frn % 2 == 0:     # w2: one counted wait per TWO fragment MFMAs
+                        self.e("WAITFRAG", "waitfrag", frag=frags[frn + 1] if "w2" in OPT else m[1])
                     if m[0] == "QK":
                         _, fr, f, ks = m
                         d = sm_ + 16 * f
@@ -202,15 +197,10 @@ class Gen:
                     frn += 1
                 else:
                     self.e(m[0], "mfma", rd=m[2], wr=m[3], frag=None, acc=False)
-            # fillers of this gap: an equal share of what is left; from gap mgap on the tile maxima take their share first
+            # fillers of this gap: an equal share of what is left
             lastgap = g == ngaps - 1
-            left = ngaps - g
-            rem = sum(x[4] for x in fill[fi:]) + sum(x[4] for x in mxq[mi:])
-            budget = rem / float(left)
-            nmax = 0
-            if mi < len(mxq) and g >= mgap:
-                nmax = len(mxq) - mi if lastgap else -(-(len(mxq) - mi) // left)
-            used = 4.0 * nmax
+            budget = sum(x[4] for x in fill[fi:]) / float(ngaps - g)
+            used = 0.0
             while fi < len(fill):
                 it = fill[fi]
                 if not lastgap and used + it[4] > budget + 2.0:
@@ -218,56 +208,117 @@ class Gen:
                 self.e(it[1], "trans" if it[0] == "E" else "valu", rd=it[2], wr=it[3], cost=it[4])
                 used += it[4]
                 fi += 1
-            if lastgap and mi < len(mxq) and g < mgap:      # short phases of the prologue: let the last QK^T MFMA retire
-                self.nop(15)
-                self.nop(15)
-                nmax = len(mxq) - mi
-            for _ in range(nmax):
-                it = mxq[mi]
-                self.e(it[1], "valu", rd=it[2], wr=it[3], cost=it[4])
-                mi += 1
-        assert fi == len(fill) and mi == len(mxq)
+        assert fi == len(fill)
 
-    # ---- the rare path: move the reference maximum of tile t --------------------------------------------------------------
-    def refmove(self, t, first):
-        s0, mx, mb, l0 = S_[t], MX, MB[t], L_[t]
-        self.nop(15)
-        self.nop(15)                       # every MFMA of the tile issued so far has retired (S, O are patched by VALU below)
-        self.e("ds_bpermute_b32 %s, %%[xora], %s" % (v(T0), v(mx)), "lds", rd=[("v", mx)], wr=[("v", T0)], frag=("X",), nops=1)
-        self.e("s_waitcnt lgkmcnt(0)", "waitall")
-        self.e("v_max_f32_e32 %s, %s, %s" % (v(T0), v(T0), v(mx)), "valu", rd=[("v", T0), ("v", mx)], wr=[("v", T0)])
-        self.e("v_add_f32_e32 %s, %s, %s" % (v(T0), v(T0), v(mb)), "valu", rd=[("v", T0), ("v", mb)], wr=[("v", T0)])
+    # ---- reference maximum of a tile: prologue (first reference) and the rare recompute of a unit --------------------------
+    def maxima(self, t):
+        """per-lane maximum of the 32 scores of tile t -> MX (two chains, then joined)"""
+        sb = S_[t]
+        def m3(d, a, b, c):
+            self.e("v_max3_f32 %s, %s, %s, %s" % (v(d), v(a), v(b), v(c)), "valu", rd=[("v", x) for x in (a, b, c)], wr=[("v", d)])
+        ca = [(MX, sb, sb + 1, sb + 2)] + [(MX, MX, sb + r, sb + r + 1) for r in range(3, 15, 2)]
+        cb = [(MX2, sb + 15, sb + 16, sb + 17)] + [(MX2, MX2, sb + r, sb + r + 1) for r in range(18, 30, 2)]
+        for x, y in zip(ca, cb):
+            m3(*x)
+            m3(*y)
+        m3(MX, MX, sb + 30, sb + 31)
+        self.e("v_max_f32_e32 %s, %s, %s" % (v(MX), v(MX), v(MX2)), "valu", rd=[("v", MX), ("v", MX2)], wr=[("v", MX)])
+
+    def newref(self, t, first):
+        """MX (scores relative to the current reference) -> new reference m (fp16-exact), T2 = delta, T3 = alpha = 2^-delta,
+        bias operand; the scores are brought to the new reference"""
+        s0, mb = S_[t], MB[t]
+        e = self.e
+        e("ds_bpermute_b32 %s, %%[xora], %s" % (v(T0), v(MX)), "lds", rd=[("v", MX)], wr=[("v", T0)], frag=("X",), nops=1)
+        e("s_waitcnt lgkmcnt(0)", "waitall")                       # (the two lane halves hold disjoint keys of the same query)
+        e("v_max_f32_e32 %s, %s, %s" % (v(T0), v(T0), v(MX)), "valu", rd=[("v", T0), ("v", MX)], wr=[("v", T0)])
+        e("v_add_f32_e32 %s, %s, %s" % (v(T0), v(T0), v(mb)), "valu", rd=[("v", T0), ("v", mb)], wr=[("v", T0)])
+        if not first:                                              # the reference never moves down after the first tile
+            e("v_max_f32_e32 %s, %s, %s" % (v(T0), v(T0), v(mb)), "valu", rd=[("v", T0), ("v", mb)], wr=[("v", T0)])
+        e("v_max_f32_e32 %s, 0xc76a6000, %s" % (v(T0), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T0)])     # -60000
+        e("v_min_f32_e32 %s, 0x476a6000, %s" % (v(T0), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T0)])     # +60000
+        e("v_cvt_f16_f32_e32 %s, %s" % (v(T1), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T1)])
+        e("v_cvt_f32_f16_e32 %s, %s" % (v(T1), v(T1)), "valu", rd=[("v", T1)], wr=[("v", T1)])             # m_new, fp16-exact
+        e("v_sub_f32_e32 %s, %s, %s" % (v(T2), v(T1), v(mb)), "valu", rd=[("v", T1), ("v", mb)], wr=[("v", T2)])   # delta
         if not first:
-            self.e("v_max_f32_e32 %s, %s, %s" % (v(T0), v(T0), v(mb)), "valu", rd=[("v", T0), ("v", mb)], wr=[("v", T0)])
-        self.e("v_max_f32_e32 %s, 0xc76a6000, %s" % (v(T0), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T0)])     # -60000
-        self.e("v_min_f32_e32 %s, 0x476a6000, %s" % (v(T0), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T0)])     # +60000
-        self.e("v_cvt_f16_f32_e32 %s, %s" % (v(T1), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T1)])
-        self.e("v_cvt_f32_f16_e32 %s, %s" % (v(T1), v(T1)), "valu", rd=[("v", T1)], wr=[("v", T1)])             # m_new, fp16-exact
-        self.e("v_sub_f32_e32 %s, %s, %s" % (v(T2), v(T1), v(mb)), "valu", rd=[("v", T1), ("v", mb)], wr=[("v", T2)])   # delta
-        if not first:
-            self.e("v_exp_f32_e64 %s, -%s" % (v(T3), v(T2)), "trans", rd=[("v", T2)], wr=[("v", T3)])           # alpha
-        self.e("v_mov_b32_e32 %s, %s" % (v(mb), v(T1)), "valu", rd=[("v", T1)], wr=[("v", mb)])
-        self.e("v_cvt_f16_f32_e64 %s, -%s" % (v(T0), v(T1)), "valu", rd=[("v", T1)], wr=[("v", T0)])
-        self.e("v_and_b32_e32 %s, %%[hmask], %s" % (v(T0), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T0)])
-        self.e("v_accvgpr_write_b32 a%d, %s" % (BB[t], v(T0)), "valu", rd=[("v", T0)], wr=[("a", BB[t])])
+            e("v_exp_f32_e64 %s, -%s" % (v(T3), v(T2)), "trans", rd=[("v", T2)], wr=[("v", T3)])           # alpha
+        e("v_mov_b32_e32 %s, %s" % (v(mb), v(T1)), "valu", rd=[("v", T1)], wr=[("v", mb)])
+        e("v_cvt_f16_f32_e64 %s, -%s" % (v(T0), v(T1)), "valu", rd=[("v", T1)], wr=[("v", T0)])
+        e("v_and_b32_e32 %s, %%[hmask], %s" % (v(T0), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T0)])
+        e("v_accvgpr_write_b32 a%d, %s" % (BB[t], v(T0)), "valu", rd=[("v", T0)], wr=[("a", BB[t])])
         for r in range(32):
-            self.e("v_sub_f32_e32 %s, %s, %s" % (v(s0 + r), v(s0 + r), v(T2)), "valu", rd=[("v", s0 + r), ("v", T2)], wr=[("v", s0 + r)])
-        if not first:
-            for la in (l0, l0 + 1):
-                self.e("v_mul_f32_e32 %s, %s, %s" % (v(la), v(la), v(T3)), "valu", rd=[("v", la), ("v", T3)], wr=[("v", la)])
-            for r in range(32):
-                a = OACC[t] + r
-                self.e("v_accvgpr_read_b32 %s, a%d" % (v(T0), a), "valu", rd=[("a", a)], wr=[("v", T0)])
-                self.e("v_mul_f32_e32 %s, %s, %s" % (v(T0), v(T0), v(T3)), "valu", rd=[("v", T0), ("v", T3)], wr=[("v", T0)])
-                self.e("v_accvgpr_write_b32 a%d, %s" % (a, v(T0)), "valu", rd=[("v", T0)], wr=[("a", a)])
+            e("v_sub_f32_e32 %s, %s, %s" % (v(s0 + r), v(s0 + r), v(T2)), "valu", rd=[("v", s0 + r), ("v", T2)], wr=[("v", s0 + r)])
+
+    def firstref(self, t):
+        """prologue: the scores of the tile's first unit have just been computed against m = 0"""
+        self.nop(15)
+        self.nop(15)
+        self.maxima(t)
+        self.newref(t, True)
         self.nop(3)
 
-    def boundary(self, t, tag, slow):
-        """compare the tile maximum of tile t with the threshold; the rare move is generated later, out of line"""
-        self.e("v_cmp_lt_f32_e32 vcc, %s, %s" % (THR, v(MX)), "valu", rd=[("v", MX)], wr=[("vcc", 0)])
-        self.e("s_cbranch_vccnz SLOW%s_%%=" % tag, "branch", target="SLOW" + tag)
-        self.label("CONT" + tag)
-        slow.append((t, tag))
+    def redo(self, t, tag, back, ksub):
+        """out of line: the unit whose softmax has just run on tile t overflowed the window above its reference.  Its
+        scores are computed again from the K sub-tile still in LDS (fragments through the tile's P registers), the
+        reference moves to the true maximum, O and l follow, and the unit's exponentials / sums / conversions run again."""
+        s0, p0, l0 = S_[t], PF[t], L_[t]
+        e = self.e
+        if back:          # the K addresses already point one stage ahead of this unit's
+            ka = [v(T0 + ks) for ks in range(4)]
+            for ks in range(4):
+                e("v_subrev_u32_e32 %s, s%d, %%[ka%d]" % (ka[ks], SKD, ks), "valu", wr=[("v", T0 + ks)])
+        else:
+            ka = ["%%[ka%d]" % ks for ks in range(4)]
+        for half in range(2):
+            if half:
+                self.nop(7)
+            for i, (ks, f) in enumerate(((2 * half, 0), (2 * half, 1), (2 * half + 1, 0), (2 * half + 1, 1))):
+                e("ds_read_b128 %s, %s offset:%d" % (vr(p0 + 4 * i, 4), ka[ks], ksub * 8192 + f * 4096), "lds",
+                  rd=[("v", T0 + ks)] if back else [], wr=R(p0 + 4 * i, 4), frag=("X",), nops=1)
+            if not half:
+                for f in range(2):
+                    e("v_mfma_f32_32x32x16_f16 %s, %s, %s, 0" % (vr(s0 + 16 * f, 16), ar(ABIAS, 4), ar(BB[t], 4)), "mfma",
+                      rd=R(ABIAS, 4, "a") + R(BB[t], 4, "a"), wr=R(s0 + 16 * f, 16), frag=None, acc=False)
+            e("s_waitcnt lgkmcnt(0)", "waitall")
+            for i, (ks, f) in enumerate(((2 * half, 0), (2 * half, 1), (2 * half + 1, 0), (2 * half + 1, 1))):
+                d = s0 + 16 * f
+                e("v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (vr(d, 16), vr(p0 + 4 * i, 4), ar(QF[t] + 4 * ks, 4), vr(d, 16)), "mfma",
+                  rd=R(p0 + 4 * i, 4) + R(QF[t] + 4 * ks, 4, "a") + R(d, 16), wr=R(d, 16), frag=None, acc=True)
+        self.nop(15)
+        self.nop(15)
+        self.maxima(t)
+        self.newref(t, False)
+        for r in range(32):
+            e("v_exp_f32_e32 %s, %s" % (v(s0 + r), v(s0 + r)), "trans", rd=[("v", s0 + r)], wr=[("v", s0 + r)])
+        for r in range(32):
+            ps = PS0 + (r & 1)
+            if r < 2:
+                e("v_add_f32_e32 %s, 0, %s" % (v(ps), v(s0 + r)), "valu", rd=[("v", s0 + r)], wr=[("v", ps)])
+            else:
+                e("v_add_f32_e32 %s, %s, %s" % (v(ps), v(ps), v(s0 + r)), "valu", rd=[("v", ps), ("v", s0 + r)], wr=[("v", ps)])
+        for q in range(16):
+            e("v_cvt_pk_f16_f32 %s, %s, %s" % (v(p0 + q), v(s0 + 2 * q), v(s0 + 2 * q + 1)), "valu",
+              rd=[("v", s0 + 2 * q), ("v", s0 + 2 * q + 1)], wr=[("v", p0 + q)])
+        e("v_add_f32_e32 %s, %s, %s" % (v(PS0), v(PS0), v(PS1)), "valu", rd=[("v", PS0), ("v", PS1)], wr=[("v", PS0)])
+        e("v_mul_f32_e32 %s, %s, %s" % (v(l0), v(l0), v(T3)), "valu", rd=[("v", l0), ("v", T3)], wr=[("v", l0)])
+        for r in range(32):
+            a = OACC[t] + r
+            e("v_accvgpr_read_b32 %s, a%d" % (v(T0), a), "valu", rd=[("a", a)], wr=[("v", T0)])
+            e("v_mul_f32_e32 %s, %s, %s" % (v(T0), v(T0), v(T3)), "valu", rd=[("v", T0), ("v", T3)], wr=[("v", T0)])
+            e("v_accvgpr_write_b32 a%d, %s" % (a, v(T0)), "valu", rd=[("v", T0)], wr=[("a", a)])
+        self.nop(3)
+        e("s_branch CONT%s_%%=" % tag, "branch", target="CONT" + tag)
+
+    def boundary(self, t, tag, back, ksub, slow):
+        """end of the softmax of a unit of tile t: the unit's row-sum partial decides (NaN included) whether the unit is redone"""
+        e = self.e
+        e("v_add_f32_e32 %s, %s, %s" % (v(PS0), v(PS0), v(PS1)), "valu", rd=[("v", PS0), ("v", PS1)], wr=[("v", PS0)])
+        if tag is not None:
+            e("v_cmp_nge_f32_e32 vcc, %s, %s" % (PSUM_LIMIT, v(PS0)), "valu", rd=[("v", PS0)], wr=[("vcc", 0)])
+            e("s_cbranch_vccnz REDO%s_%%=" % tag, "branch", target="REDO" + tag)
+            self.label("CONT" + tag)
+            slow.append((t, tag, back, ksub))
+        e("v_add_f32_e32 %s, %s, %s" % (v(L_[t]), v(L_[t]), v(PS0)), "valu", rd=[("v", L_[t]), ("v", PS0)], wr=[("v", L_[t])])
 
     # ---- DMA of one 128-key stage (this wave's four 1-KiB pieces) --------------------------------------------------------
     def dma_stage(self):
@@ -296,14 +347,17 @@ class Gen:
         s("s_cmp_ge_u32 s%d, %%[ldsend]" % SDST, "salu")
         s("s_cselect_b32 s%d, s%d, s%d" % (SDST, STMP, SDST), "salu")
 
-    def advance(self, pos, names):
-        """fragment addresses -> next LDS buffer of the ring (pos = byte offset of the buffer they point into)"""
+    def advance(self, pos, names, keep):
+        """fragment addresses -> next LDS buffer of the ring (pos = byte offset of the buffer they point into); keep: an
+        SGPR that remembers the step (the recompute path of a unit one stage back subtracts it again)"""
         s = self.e
         s("s_add_u32 s%d, s%d, %d" % (pos, pos, STAGE), "salu")
         s("s_cmp_eq_u32 s%d, %d" % (pos, NBUF * STAGE), "salu")
         s("s_mov_b32 s%d, %d" % (STMP, STAGE), "salu")
         s("s_cselect_b32 s%d, 0x%x, s%d" % (STMP, (-(NBUF - 1) * STAGE) & 0xffffffff, STMP), "salu")
         s("s_cselect_b32 s%d, 0, s%d" % (pos, pos), "salu")
+        if keep is not None:
+            s("s_mov_b32 s%d, s%d" % (keep, STMP), "salu")
         for nm in names:
             s("v_add_u32_e32 %%[%s], s%d, %%[%s]" % (nm, STMP, nm), "valu", rd=[("op", nm)], wr=[("op", nm)])
 
@@ -331,8 +385,8 @@ class Gen:
         s("v_accvgpr_write_b32 a%d, %s" % (ABIAS, v(T0)), "valu", rd=[("v", T0)], wr=[("a", ABIAS)])
         for t in "AB":
             s("v_mov_b32_e32 %s, 0" % v(L_[t]), "valu", wr=[("v", L_[t])])
-            s("v_mov_b32_e32 %s, 0" % v(L_[t] + 1), "valu", wr=[("v", L_[t] + 1)])
             s("v_mov_b32_e32 %s, 0" % v(MB[t]), "valu", wr=[("v", MB[t])])
+        s("s_mov_b32 s%d, 0" % SKD, "salu")
         self.ckpt()                                   # 2: after the register initialisation
         # ---- stage 0 has been issued by the kernel; publish it, start stage 1
         s("s_waitcnt vmcnt(0)", "waitvm")
@@ -344,22 +398,23 @@ class Gen:
         self.label("NOST1")
         self.ckpt()                                   # 4: after the DMA of stage 1
         # ---- P0: QK_A(0), first reference of A.  P1 = alpha(0): sm_A(0) | QK_B(0), first reference of B
-        self.phase("P0", None, "A", True, False, 0, 0, True, False, K(0))
+        self.phase("P0", None, "A", True, False, 0, 0, False, K(0))
         self.ckpt()                                   # 5: after P0
-        self.refmove("A", True)
+        self.firstref("A")
         self.ckpt()                                   # 6: after the first reference of A
-        self.phase("P1", "A", "B", True, False, 0, 0, True, True, K(1))
-        self.refmove("B", True)
+        self.phase("P1", "A", "B", True, False, 0, 0, True, K(1))
+        self.boundary("A", None, False, 0, slow)      # (scores <= 0 after the first reference: no check)
+        self.firstref("B")
         self.ckpt()                                   # 7: after P1 and the first reference of B
-        # ---- loop over stages
+        # ---- loop over stages.  boundary(tile, tag, back, ksub): where the K sub-tile of the unit just exponentiated lives
         self.label("LOOP")
         self.ckpt()                                   # 8
-        self.phase("beta(2s)", "B", "A", True, True, 1, 0, True, True, K(1))
+        self.phase("beta(2s)", "B", "A", True, True, 1, 0, True, K(1))
         self.ckpt()                                   # 9
-        self.boundary("A", "0", slow)
+        self.boundary("B", "0", False, 0, slow)
         self.ckpt()                                   # 10
-        self.phase("alpha(2s+1)", "A", "B", True, True, 1, 0, True, True, None)
-        self.boundary("B", "1", slow)
+        self.phase("alpha(2s+1)", "A", "B", True, True, 1, 0, True, None)
+        self.boundary("A", "1", False, 1, slow)
         self.ckpt()                                   # 11
         s("s_add_u32 s%d, s%d, 1" % (STMP2, SIT), "salu")
         s("s_cmp_eq_u32 s%d, %%[nst]" % STMP2, "salu")
@@ -371,31 +426,31 @@ class Gen:
         s("s_cbranch_scc0 NODMA_%=", "branch", target="NODMA")
         self.dma_stage()
         self.label("NODMA")
-        self.advance(SKPOS, ["ka0", "ka1", "ka2", "ka3"])
-        self.phase("beta(2s+1)", "B", "A", True, True, 0, 1, True, False, K(0))
-        self.boundary("A", "2", slow)
-        self.phase("alpha(2s+2)", "A", "B", True, True, 0, 1, True, True, K(1))
-        self.boundary("B", "3", slow)
-        self.advance(SVPOS, ["va0", "va1"])
+        self.advance(SKPOS, ["ka0", "ka1", "ka2", "ka3"], SKD)
+        self.phase("beta(2s+1)", "B", "A", True, True, 0, 1, False, K(0))
+        self.boundary("B", "2", True, 1, slow)        # B(2s+1): K of stage s, the addresses are at stage s+1
+        self.phase("alpha(2s+2)", "A", "B", True, True, 0, 1, True, K(1))
+        self.boundary("A", "3", False, 0, slow)
+        self.advance(SVPOS, ["va0", "va1"], None)
         s("s_add_u32 s%d, s%d, 1" % (SIT, SIT), "salu")
         s("s_branch LOOP_%=", "branch", target="LOOP")
         # ---- tail
         self.label("TAIL")
         self.ckpt()                                   # 12
-        self.phase("tail beta", "B", "A", False, True, 0, 1, False, False, V(1))
+        self.phase("tail beta", "B", "A", False, True, 0, 1, False, V(1))
+        self.boundary("B", "4", False, 1, slow)
         self.ckpt()                                   # 13
-        self.phase("tail pv_B", None, "B", False, True, 0, 1, False, True, None)
+        self.phase("tail pv_B", None, "B", False, True, 0, 1, True, None)
         self.ckpt()                                   # 14
         self.nop(15)
         self.nop(15)
-        s("v_add_f32_e32 %%[la], %s, %s" % (v(L_["A"]), v(L_["A"] + 1)), "valu", rd=R(L_["A"], 2))
-        s("v_add_f32_e32 %%[lb], %s, %s" % (v(L_["B"]), v(L_["B"] + 1)), "valu", rd=R(L_["B"], 2))
+        s("v_mov_b32_e32 %%[la], %s" % v(L_["A"]), "valu", rd=R(L_["A"], 1))
+        s("v_mov_b32_e32 %%[lb], %s" % v(L_["B"]), "valu", rd=R(L_["B"], 1))
         s("s_branch END_%=", "branch", target="END")
-        # ---- out-of-line reference moves
-        for t, tag in slow:
-            self.label("SLOW" + tag)
-            self.refmove(t, False)
-            s("s_branch CONT%s_%%=" % tag, "branch", target="CONT" + tag)
+        # ---- out-of-line: units whose scores left the window above their reference
+        for t, tag, back, ksub in slow:
+            self.label("REDO" + tag)
+            self.redo(t, tag, back, ksub)
         self.label("END")
 
     # ---- resolve the WAITFRAG markers into counted lgkmcnt waits ----------------------------------------------------------
@@ -486,6 +541,17 @@ class Gen:
                 elif i.kind == "valu":
                     last_valu_wr[r] = pos
             pos += ws(i)
+        # no named register is read before the statement has written it (Q fragments a[64:95] come from the kernel)
+        written = set(("a", i) for i in range(QF["A"], QF["B"] + 16))
+        for i in self.ins:
+            if i.kind in ("label", "comment"):
+                continue
+            for r in i.rd:
+                if r[0] in ("v", "a") and r not in written:
+                    print("UNINITIALISED %s read by: %s" % (r, i.text))
+                    nerr += 1
+                    written.add(r)
+            written.update(i.wr)
         # ring contents: the fragment an MFMA consumes is the one last read into its slot, and it has been waited for
         slotfrag, pending = {}, []
         for i in walk:
@@ -512,8 +578,33 @@ class Gen:
 
     def text(self):
         lines = []
+        knob = os.environ.get("ATTN_GEN_KNOB", "").split("+")    # timing experiments only (tools/micro/attn_pipe_knobs.sh)
         for i in self.ins:
             if i.kind == "comment":
+                continue
+            if knob != [""] and i.kind == "branch" and i.meta["target"].startswith("REDO"):
+                continue          # every knob build: the reference never moves (removed ingredients leave garbage maxima)
+            if "nolds" in knob and (i.kind == "waitlgkm" or (i.kind == "lds" and i.meta["frag"][0] != "X")):
+                continue
+            if "nokread" in knob and i.kind == "lds" and i.meta["frag"][0] == "K":
+                continue
+            if "novread" in knob and i.kind == "lds" and i.meta["frag"][0] == "V":
+                continue
+            if "nowait" in knob and i.kind == "waitlgkm":
+                continue
+            if "novalu" in knob and i.kind in ("valu", "trans") and "cost" in i.meta:
+                continue
+            if "noexp" in knob and i.kind == "trans" and "cost" in i.meta:
+                continue
+            for cls, key in (("noadd", "v_add_f32"), ("nocvt", "v_cvt_pk")):
+                if cls in knob and "cost" in i.meta and i.text.startswith(key):
+                    i = None
+                    break
+            if i is None:
+                continue
+            if "nomfma" in knob and i.kind == "mfma":
+                continue
+            if "nobar" in knob and i.kind in ("barrier", "waitvm", "vmem"):
                 continue
             lines.append('"' + i.text + NL + '"')
         return " \\\n  ".join(lines)

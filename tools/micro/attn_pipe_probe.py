@@ -24,5 +24,12 @@ qf, kf, vf = (t.float().cpu().reshape(nb, S, heads, 64).transpose(1, 2) for t in
 ref = F.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(nb * S, C)
 err = (out.float().cpu() - ref).abs()
 print("S", S, "max err", err.max().item(), "nan", torch.isnan(out).sum().item(), "ref scale", ref.abs().max().item())
-bad = (err > 5e-3).nonzero()
-print("bad entries", bad.shape[0], bad[:12].tolist())
+bad = (err > 5e-3)
+rows = bad.any(1).nonzero().flatten()
+print("bad entries", int(bad.sum()), "bad rows", rows.numel(), "first", rows[:8].tolist(), "last", rows[-8:].tolist())
+if rows.numel():
+    import collections
+    print("bad rows by (row // 32):", sorted(collections.Counter((rows // 32).tolist()).items()))
+    r0 = int(rows[0])
+    print("row", r0, "bad cols", bad[r0].nonzero().flatten().tolist()[:70])
+    print(" got", out[r0, :8].float().cpu().tolist(), "\n ref", ref[r0, :8].tolist())
