@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--inference-steps", type=int, default=25)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet config (plumbing checks only; not a valid number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="cpu_baseline: time ONE full configs[1] forward of the fp32 oracle on this box's host in this run "
+                         "(minutes) instead of quoting the committed round-2 measurement beside the bounded live sample")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed) VAE encode / decode measurement")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--lk", action="store_true",
@@ -88,6 +91,19 @@ def build_unet(dev, tiny, lk=False):
     return m
 
 
+def kernels_sha16():
+    """fingerprint of the kernel sources (lkgd_amd/csrc/*.hip, *.h, *.inc): stamped into profiles/pmc_traffic.json when the
+    PMC passes are summarised (tools/pmc_summary.py) and compared here, so a stale traffic figure says so"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(REPO, "lkgd_amd", "csrc", "*"))):
+        if fn.endswith((".hip", ".h", ".inc")):
+            with open(fn, "rb") as f:
+                h.update(os.path.basename(fn).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args):
     """fp32 oracle on the host cores, bounded sample: ONE forward of the real-shaped UNet on half the C1 geometry
     (CFG batch 2 x 2 frames x 32x32 latent = 1.19 algorithmic TFLOP, 8-27 s on the boxes seen so far), extrapolated to
@@ -121,12 +137,20 @@ def cpu_baseline(args):
         return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "tiny config (invalid)"}
     tflops = tflop_sample / dt
     fps = args.frames / (args.inference_steps * UNET_TFLOP_C2 / tflops)
-    full = None      # the ONE full C2 forward of the same oracle timed on a GPU box's host (tools/cpu_full_forward.py, committed log)
-    try:
-        with open(os.path.join(REPO, "profiles", "r02_cpu_full_forward.json")) as f:
-            full = json.load(f)
-    except (OSError, ValueError):
-        pass
+    full, full_src = None, None
+    if getattr(args, "cpu_full", False):       # time the ONE full configs[1] forward of the oracle in THIS run (minutes)
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from cpu_full_forward import run_full_forward
+        full = run_full_forward(args.frames, args.height // 8, args.width // 8, verbose=False)
+        full_src = "measured by this run (--cpu-full)"
+    else:            # ... or quote the one timed on a GPU box's host in round 2 (tools/cpu_full_forward.py, committed log)
+        try:
+            with open(os.path.join(REPO, "profiles", "r02_cpu_full_forward.json")) as f:
+                full = json.load(f)
+            full_src = "NOT measured by this run: quoted from profiles/r02_cpu_full_forward.json (tools/cpu_full_forward.py " \
+                       "on a GPU box's host, round 2); this run measured `live_sample` only - pass --cpu-full to time it here"
+        except (OSError, ValueError):
+            pass
     live = (f"oracle fp32 (torch eager), one UNet forward of the real-shaped SVD UNet at CFG-batch 2 x 2 frames x 32x32 latent "
             f"(half of config 1's geometry, {tflop_sample:.2f} TFLOP) in {dt:.1f} s = {tflops:.3f} TFLOP/s on {cores} threads "
             f"(os.cpu_count={os.cpu_count()}) -> {fps:.6f} C2-equivalent frames/s by FLOPs; model build {t_build:.0f} s not counted")
@@ -135,13 +159,12 @@ def cpu_baseline(args):
         # extrapolates 3x low); the bounded sample of this run is kept beside it
         fps_full = args.frames / (args.inference_steps * float(full["seconds"]))
         return {"value": round(fps_full, 6), "unit": "frames/s (one full configs[1] UNet forward of the fp32 oracle, measured, x 25 steps / 14 frames)",
-                "cores": full.get("threads", cores), "kind": "port",
+                "cores": full.get("threads", cores), "kind": "port", "value_source": full_src,
                 "sample": f"ONE full configs[1] forward (CFG 2 x 14 frames x 72x128 latent, {UNET_TFLOP_C2:.2f} TFLOP) of the fp32 oracle "
-                          f"in {float(full['seconds']):.1f} s on a GPU box's host (tools/cpu_full_forward.py, "
-                          f"profiles/r02_cpu_full_forward.json)",
+                          f"in {float(full['seconds']):.1f} s on {full.get('threads', cores)} host threads",
                 "live_sample": live, "live_sample_value": round(fps, 6)}
     return {"value": round(fps, 6), "unit": "frames/s (C2-equivalent, extrapolated by algorithmic FLOPs)",
-            "cores": cores, "kind": "port", "sample": live}
+            "cores": cores, "kind": "port", "value_source": "measured by this run (bounded sample)", "sample": live}
 
 
 def vae_stages(dev, args, latents, loop_s_per_clip):
@@ -426,10 +449,17 @@ def main():
         tot_ms = sum(s.elapsed_time(e) for s, e, _ in events)
         tot_flop = sum(f for _, _, f in events)
         achieved = tot_flop / (tot_ms * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMC itself)
+        traffic = traffic_src = None      # HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMC itself)
         try:
             with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["gemm_family_bytes_per_launch"]
+                pj = json.load(f)
+            traffic = pj["gemm_family_bytes_per_launch"]
+            here = kernels_sha16()
+            traffic_src = {"file": "profiles/pmc_traffic.json", "kernels_sha16_when_collected": pj.get("kernels_sha16"),
+                           "kernels_sha16_now": here, "same_kernel_sources": pj.get("kernels_sha16") == here}
+            if pj.get("kernels_sha16") != here:
+                print("bench.py: roofline.traffic comes from PMC passes over OTHER kernel sources (profiles/pmc_traffic.json: "
+                      f"{pj.get('kernels_sha16')}, this tree: {here}) - rerun tools/prof_pmc_traffic.sh", file=sys.stderr)
         except (OSError, KeyError, ValueError):
             pass
         # sharded runs time the GEMM launches of every 5th Euler step only (DistDenoiser.event_stride): scale the share
@@ -439,7 +469,7 @@ def main():
         roofline = {"bound": "mfma", "kernel": "lkgd_gemm_{wide,resw,rowpanel,stream}_kernel + lkgd_gemm_kernel (MFMA GEMM / implicit-conv family)",
                     "achieved": round(achieved, 2),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "launches": len(events),
+                    "traffic": traffic, "traffic_source": traffic_src, "launches": len(events),
                     "avg_launch_us": round(tot_ms * 1e3 / len(events), 2),
                     "gemm_share_of_wall": round(tot_ms * 1e-3 * scale * args.steps / max(clips_sampled, 1) / dt, 3),
                     "launches_timed": f"every GEMM launch of {clips_sampled} of the {args.steps} timed clips" + (

@@ -143,7 +143,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
         if blk > 0 and int(colstats) % blk == 0:
             buf = torch.empty((M + blk - 1) // blk, N // 2, 2, dtype=torch.float32, device=out.device)   # channel pairs
             d.colstats = buf.data_ptr()
-            out._lkgd_colstats = (buf, blk)
+            out._lkgd_colstats = (buf, blk, out._version)      # see _stats_from_cols: void once `out` is written again
     ev = GEMM_EVENTS
     if ev is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -170,7 +170,11 @@ def _stats_from_cols(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int
     cs1 = getattr(x1, "_lkgd_colstats", None) if x1 is not None else None
     if cs0 is None or (x1 is not None and cs1 is None):
         return None
-    (b0, k0), (b1, k1) = cs0, (cs1 if cs1 is not None else (None, 1))
+    # the sums describe the tensor as its producing GEMM wrote it: any in-place torch op since then (the version counter
+    # moves) voids them - the caller falls back to the read pass instead of normalising with stale statistics
+    if cs0[2] != x0._version or (cs1 is not None and cs1[2] != x1._version):
+        return None
+    (b0, k0), (b1, k1) = cs0[:2], (cs1[:2] if cs1 is not None else (None, 1))
     if (rows_per_sample % k0 or rows_per_sample % k1 or 2 * b0.shape[1] != x0.shape[1] or
             (b1 is not None and 2 * b1.shape[1] != x1.shape[1]) or ((x0.shape[1] + (x1.shape[1] if x1 is not None else 0)) // 32) % 2):
         return None

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: duplicates coverage at a multiple of the cost; runs only with LKGD_SLOW=1")
 
 
 @pytest.fixture(scope="session")
@@ -22,6 +23,11 @@ def golden_dir():
 def pytest_collection_modifyitems(config, items):
     """a bare `pytest` on a box without a GPU skips the `gpu` tests instead of failing them (the driver selects with -m)"""
     import torch
+    if not os.environ.get("LKGD_SLOW"):
+        slow = pytest.mark.skip(reason="slow duplicate of a default test (set LKGD_SLOW=1 to run it)")
+        for it in items:
+            if "slow" in it.keywords:
+                it.add_marker(slow)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="needs a real MI355X (torch.cuda.is_available() is False)")

@@ -10,9 +10,13 @@ F14_SEED = 161            # inputs of the 14-frame real-width loop fixtures (rou
 FULLRES_GEOM = dict(B=2, F=2, H=72, W=128)
 
 
-def fullres_inputs(seed=FULLRES_SEED + 1, lk=False):
+FULLRES_F14_SEED = 171    # inputs of the ONE-forward fixture at the headline geometry itself: CFG 2 x 14 frames x 72 x 128 (round 4)
+
+
+def fullres_inputs(seed=FULLRES_SEED + 1, lk=False, frames=None):
     g = torch.Generator().manual_seed(seed)
     B, F, H, W = (FULLRES_GEOM[k] for k in "BFHW")
+    F = frames or F
     d = {"sample": torch.randn(B, F, 8, H, W, generator=g).half().float(), "t": torch.tensor(0.875),
          "enc": torch.randn(B, 1, 1024, generator=g).half().float(), "ids": torch.tensor([[6.0, 127.0, 0.02]] * B)}
     if lk:

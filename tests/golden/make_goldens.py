@@ -948,6 +948,29 @@ def gen_unet_fullres(ref_stock):
     print("unet fullres: out std %.4f, checksum %.6e" % (out["out"].std(), out["checksum"]))
 
 
+def gen_unet_fullres_f14(ref_stock):
+    """ONE forward of the reference's stock UNet at the geometry of BASELINE.json configs[1] ITSELF: CFG 2 x 14 frames x 72 x 128
+    latent (N = 28 frame-images, S = 9216; 89.7 TFLOP in fp32 on the CPU, minutes).  The output is stored in fp16 (2 MB; its
+    rounding, 5e-4 relative, is far inside the 1e-2 gate) beside fp64 sums of the fp32 result."""
+    from fullres_cases import FULLRES_F14_SEED
+    from oracle.unet import SVD_CONFIG
+    inp = fullres_inputs(seed=FULLRES_F14_SEED, frames=14)
+    with torch.no_grad():
+        m = ref_stock.UNetSpatioTemporalConditionControlNetModel(**SVD_CONFIG.__dict__)
+        ou.init_weights_(m, C1_SEED)
+        for p in m.parameters():
+            p.copy_(p.half().float())
+        import time
+        t0 = time.time()
+        y = m(inp["sample"], inp["t"], inp["enc"], added_time_ids=inp["ids"], return_dict=False)[0]
+        print("reference forward at 2 x 14 x 72 x 128: %.0f s" % (time.time() - t0))
+        out = {"checksum": torch.tensor(checksum(m), dtype=torch.float64), "out_f16": y.half(),
+               "out_sum": y.double().sum().reshape(1), "out_abs_sum": y.double().abs().sum().reshape(1),
+               "out_std": y.double().std().reshape(1)}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_fullres_f14.safetensors"))
+    print("unet fullres f14: out std %.4f, checksum %.6e" % (y.std(), out["checksum"]))
+
+
 def gen_unet_fullres_lk(ref_lk, fsm_mod):
     """configs[2] at full resolution: ONE forward of the reference's LKGD UNet (unet_spatio_temporal_condition.py:448-693,
     domain / flow features) with the patch_FSM hook active in every spatial transformer block (patch_FSM.py:380-441),
@@ -1002,7 +1025,7 @@ def main():
                              "models.unet_spatio_temporal_condition_controlnet")
         pipe_mod = load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans")
         return gen_loop_f14(pipe_mod, ref_stock, sched_mod, only == "loop_f14_cfg")
-    if only in ("loop25", "loop25_c1", "unet_fullres", "unet_fullres_lk"):     # round-2 fixtures, one at a time
+    if only in ("loop25", "loop25_c1", "unet_fullres", "unet_fullres_lk", "unet_fullres_f14"):     # one at a time
         for m in ("models", "utils"):
             _mod(m)
         sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
@@ -1010,6 +1033,8 @@ def main():
                              "models.unet_spatio_temporal_condition_controlnet")
         if only == "unet_fullres":
             return gen_unet_fullres(ref_stock)
+        if only == "unet_fullres_f14":
+            return gen_unet_fullres_f14(ref_stock)
         if only == "unet_fullres_lk":
             ref_lk = load_ref("models/unet_spatio_temporal_condition.py", "models.unet_spatio_temporal_condition")
             _mod("patch")

@@ -64,6 +64,7 @@ def _build(dev):
 
 def _worker(rank, world, port, frames, guidance_on, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))   # the ranks share the box's host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd.dist_run import DistDenoiser
@@ -99,6 +100,7 @@ def _worker_cn(rank, world, port, frames, q):
     """BASELINE.json configs[3]-style combination under sharding: the LKGD UNet (domain / flow features) with the
     ControlNet-SVD encoder in the loop (pipeline_stable_video_diffusion_controlnet.py:582-607)"""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))   # the ranks share the box's host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd import controlnet as pc
@@ -158,6 +160,7 @@ def test_sharded_controlnet_lk_loop_equals_single_process(world, frames):
 def _worker_dit(rank, world, port, q):
     """configs[4] under sharding: the CogVideoX DiT loop, CFG-parallel x latent-frame slices (3 latent frames over (2, 1))"""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))   # the ranks share the box's host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd import cogvideox as pc
@@ -204,7 +207,8 @@ def test_sharded_dit_loop_equals_single_process(world):
 
 
 @pytest.mark.parametrize("world,frames,guidance_on,gather", [(2, 4, True, False), (4, 5, True, False), (2, 5, False, False),
-                                                             (4, 6, False, False), (4, 6, False, True)])
+                                                             (4, 6, False, False),
+                                                             (4, 6, False, True)])
 def test_sharded_loop_equals_single_process(world, frames, guidance_on, gather, monkeypatch):
     """gather = False: the temporal attention re-shards by pixels (all-to-all, the default; the 1x1 level of this tiny net has
     fewer pixels than shards and keeps the gathered form); True: LKGD_TEMPORAL_GATHER=1, all-gather of the hidden states"""

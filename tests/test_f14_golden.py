@@ -61,6 +61,7 @@ def _worker(rank, world, port, gpath, wpath, q):
     import time
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))   # the ranks share the box's host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd import unet as pu
@@ -88,15 +89,18 @@ def _worker(rank, world, port, gpath, wpath, q):
 
 
 def test_sharded_cfg_x_7_7_loop_vs_reference_golden(golden, golden_dir, c1_hip_model):
-    """4 ranks = CFG-parallel x frame slices (7, 7) of the 14 frames (the 4-GPU layout of DESIGN.md section 6): temporal
-    attention over gathered frames, Conv3d halos, all-reduced temporal GroupNorm sums - every rank's result against the
-    reference's fp32 run"""
+    """4 ranks = CFG-parallel x frame slices (7, 7) of the 14 frames (the 4-GPU layout of DESIGN.md section 6): the temporal
+    attention's all-to-all re-sharding, Conv3d halos, all-reduced temporal GroupNorm sums - every rank's result against the
+    REFERENCE's fp32 run.  The uneven layouts with interior ranks - CFG x (4,4,3,3) on 8 ranks, CFG x (5,5,4) on 6 - cannot run
+    here: a GPU box of this pool admits 6 processes on the card INCLUDING this pytest process (tried in round 4: `process
+    guard`, 7 > 6), and the reference loop has no guidance-free branch to compare a 4-rank (4,4,3,3) run with.  Those splits
+    stay pinned against the single-process loop (test_dist_gpu.py: world 4, 5 / 6 frames -> (3,2) / CFG-less (2,2,1,1))."""
+    world = 4
     import torch.multiprocessing as mp
     from test_dist_gpu import _collect
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    world = 4
     gpath = os.path.join(golden_dir, "loop_f14_cfg.safetensors")
     # the ranks load the session model's fp16 weights from shared memory (3 GB) instead of re-drawing 1.5 B parameters each
     wpath = "/dev/shm/lkgd_f14_weights_%d.pt" % os.getpid()

@@ -3,6 +3,7 @@ REAL width, against ONE forward of the reference's own top-level UNets run in fp
 (tests/golden/make_goldens.py::gen_unet_fullres / gen_unet_fullres_lk; CFG 2 x 2 frames -> N = 4 frame-images):
 
 * unet_fullres.safetensors     <- models/unet_spatio_temporal_condition_controlnet.py:358-508 (stock signature)
+* unet_fullres_f14.safetensors <- the same stock forward at the headline geometry itself: CFG 2 x 14 frames (round 4)
 * unet_fullres_lk.safetensors  <- models/unet_spatio_temporal_condition.py:448-693 (domain / flow features) without and
                                   with the patch_FSM hook (patch/patch_FSM.py:380-441) active in all 16 spatial blocks
 
@@ -16,7 +17,7 @@ import pytest
 import torch
 from safetensors.torch import load_file
 
-from golden.fullres_cases import FULLRES_LK_SEED, fullres_inputs, fullres_tracks, seed_conv_fuse_
+from golden.fullres_cases import FULLRES_F14_SEED, FULLRES_LK_SEED, fullres_inputs, fullres_tracks, seed_conv_fuse_
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -58,6 +59,22 @@ def test_stock_unet_full_resolution_vs_reference_golden(golden_dir, c1_oracle_mo
     i = fullres_inputs()
     out = m(i["sample"].to(DEV), i["t"].to(DEV), i["enc"].to(DEV), added_time_ids=i["ids"].to(DEV), return_dict=False)[0]
     _gate(out, g["out"], "stock UNet @ 72x128")
+    assert abs(out.double().sum().item() - g["out_sum"].item()) <= 2e-3 * g["out_abs_sum"].item()
+
+
+def test_stock_unet_headline_geometry_vs_reference_golden(golden_dir, c1_oracle_model, c1_hip_model):
+    """The headline workload ITSELF (round 4): ONE forward at CFG 2 x 14 frames x 72 x 128 - every kernel at the very shapes
+    bench.py times (28 frame-images, S = 9216 spatial tokens, 14-frame temporal attention / Conv3d / GroupNorm at 9216 pixels)
+    - against the reference's own `forward` (unet_spatio_temporal_condition_controlnet.py:358-508) run in fp32 on the CPU
+    (make_goldens.py::gen_unet_fullres_f14; the fixture stores the result rounded to fp16 and fp64 sums of the fp32 result)."""
+    g = load_file(os.path.join(golden_dir, "unet_fullres_f14.safetensors"))
+    ck = float(sum(p.detach().double().abs().sum() for p in c1_oracle_model.parameters()))
+    assert abs(ck - g["checksum"].item()) <= 1e-9 * ck, "regenerated weights differ from the ones the reference ran with"
+    i = fullres_inputs(seed=FULLRES_F14_SEED, frames=14)
+    out = c1_hip_model(i["sample"].to(DEV), i["t"].to(DEV), i["enc"].to(DEV), added_time_ids=i["ids"].to(DEV),
+                       return_dict=False)[0]
+    assert out.shape == (2, 14, 4, 72, 128)
+    _gate(out, g["out_f16"].float(), "stock UNet @ 2 x 14 x 72 x 128")
     assert abs(out.double().sum().item() - g["out_sum"].item()) <= 2e-3 * g["out_abs_sum"].item()
 
 

@@ -147,6 +147,86 @@ def test_full_size_loop_properties(full_pipe):
     assert torch.isfinite(f.float()).all() and f.float().abs().max() < 1e4
 
 
+def test_full_size_lk_joint_and_fsm_hook_properties():
+    """BASELINE.json configs[2] at FULL size: the LKGD UNet (domain / flow features) on TWO clips of 14 frames x 72 x 128 (the
+    [start, end] pair of the trans pipelines: CFG batch 4 x 14 = 56 frame-images), with the `patch` joint-attention hooks
+    (spatial + temporal, masks [0,1,0,1], utils/util.py:600-606; patch/patch.py:438-501) and with the patch_FSM track hook
+    (patch_FSM.py:380-441).  Properties: finite, bitwise deterministic, zero-initialised hooks are the identity, hooks with
+    weights change the result, switching them off restores it."""
+    import bench
+    from lkgd_amd import patch, patch_FSM
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+    dev = torch.device(DEV)
+    unet = bench.build_unet(dev, tiny=False, lk=True)
+    pipe = StableVideoDiffusionPipeline(unet=unet)
+    lat0, img, emb, ids = bench.synthetic_inputs(dev, 14, H, W)
+    lat0 = torch.cat([lat0, 0.9 * lat0.flip(1)])
+    img = torch.stack([img[0], img[0], img[1], 0.8 * img[1]])        # [u1, u2, c1, c2]
+    emb = torch.stack([emb[0], emb[0], emb[1], 0.8 * emb[1]])
+    ids = ids[:1].repeat(4, 1)
+    g = torch.Generator().manual_seed(12348)
+    dom = torch.randn(1, 1, 1000, generator=g).half().to(dev)
+    flow = torch.randn(1, 1, 1000, generator=g).half().to(dev)
+    dom, flow = torch.cat([dom, 0.7 * dom] * 2), torch.cat([flow, 0.6 * flow] * 2)
+
+    def run():
+        pipe.scheduler.set_timesteps(2)
+        s0 = float(pipe.scheduler.init_noise_sigma)
+        return pipe.denoise((lat0 * s0).half(), img, emb, ids, 2, 1.0, 3.0, domain_features=dom, flow_features=flow)
+
+    base = run()
+    assert base.shape == (2, 14, 4, H, W) and torch.isfinite(base.float()).all()
+    # ---- patch.py joint attention, spatial + temporal
+    patch.apply_patch(pipe, with_temporal_block=True)
+    patch.initialize_joint_layers(pipe)
+    patch.set_joint_attention_mask(pipe, [0, 1, 0, 1])
+    # zero-initialised conv1n: the joint branch adds exactly nothing; with the hooks on the blocks take their unfused paths
+    # (separate LayerNorm / projections instead of the folded / fused kernels), so the 2-step loop differs at fp16 level
+    noise = _rel(run(), base)
+    print(f"\nzero-initialised joint hooks vs no hooks: rel L2 {noise:.3e}")
+    assert noise < 8e-3
+    with torch.no_grad():
+        gw = torch.Generator().manual_seed(12350)
+        for name, prm in unet.named_parameters():
+            if "attn1n" in name or "conv1n" in name:
+                prm.copy_((torch.randn(prm.shape, generator=gw) * (0.5 / max(prm.shape[-1], 1) ** 0.5)).to(prm))
+    unet.invalidate()
+    a = run()
+    assert torch.isfinite(a.float()).all() and torch.equal(a, run())
+    print(f"joint hooks with weights vs no hooks: rel L2 {_rel(a, base):.3e}")
+    assert _rel(a, base) > max(2e-2, 4 * noise)           # the partner clip reaches the result
+    # (set_joint_attention(False) would not last - the loop switches the hooks on at every step, pipeline_..._trans.py:555 -
+    # and joint_scale only reaches the spatial branch, patch.py:500 vs :654: removing the patch is what restores the model)
+    patch.remove_patch(pipe)
+    assert _rel(run(), base) < 8e-3
+    # ---- patch_FSM.py track hook between the two clips' frame-images (even / odd batch entries)
+    patch_FSM.apply_patch(pipe, with_spatial_block=True, with_temporal_block=False)
+    patch_FSM.initialize_joint_layers(pipe)
+    pairs, points = 4 * 14 // 2, 1024
+    res = (2 * H, 2 * W)
+    gt = torch.Generator().manual_seed(12351)
+    src = torch.stack([torch.randint(0, res[1], (pairs, points), generator=gt),
+                       torch.randint(0, res[0], (pairs, points), generator=gt)], -1).float()
+    dst = (src + torch.randint(-9, 10, (pairs, points, 2), generator=gt)).float()
+    vis = (torch.rand(pairs, points, generator=gt) > 0.2).float()
+    patch_FSM.update_patch(pipe, track=(src.to(dev), dst.to(dev), vis.to(dev)), track_res=res)
+    patch_FSM.set_joint_attention(pipe, True)
+    assert _rel(run(), base) < 8e-3                       # zero-initialised conv_fuse: identity
+    with torch.no_grad():
+        for _, b in unet.named_modules():
+            if hasattr(b, "conv_fuse"):
+                w, bias = b.conv_fuse.weight, b.conv_fuse.bias
+                w.copy_((torch.randn(w.shape, generator=gw) / w[0].numel() ** 0.5).to(w))
+                bias.copy_((0.1 * torch.randn(bias.shape, generator=gw)).to(bias))
+    unet.invalidate()
+    f = run()
+    assert torch.isfinite(f.float()).all() and torch.equal(f, run())
+    print(f"FSM hook with weights vs no hooks: rel L2 {_rel(f, base):.3e}")
+    assert _rel(f, base) > max(2e-2, 4 * noise)
+    patch_FSM.remove_patch(pipe)
+    assert _rel(run(), base) < 8e-3
+
+
 def test_full_size_temporal_attention_and_layernorm_samples():
     """round 3: the two hot ops the full-size suite only saw through loop properties - temporal attention over all F = 14 frames
     at HW = 9216 (B = 2, 5 heads: 92 160 (pixel, head) problems) and LayerNorm over 258 048 rows - against fp32 on a strided

@@ -762,6 +762,12 @@ def test_groupnorm_statistics_from_gemm_epilogues():
         sums = ops.groupnorm_sums(out, x1, nsamples, rows)
         cnt = rows * full.shape[1] // 32
         assert torch.allclose(sums.cpu()[..., 0] / cnt, ref[..., 0], rtol=1e-3, atol=1e-4)
+        if x1 is None:       # an in-place update of the tensor voids the attached sums: the statistics follow the NEW values
+            keep = out.clone()
+            out.mul_(0.5)
+            half = ops.groupnorm_stats(out, None, nsamples, rows, 1e-5)
+            assert torch.allclose(half.cpu(), stats_ref(out.cpu(), nsamples, rows), rtol=1e-3, atol=1e-4)
+            out.copy_(keep)
 
     # (small shapes: the 256x320 program is forced - the automatic dispatch would give 16 tiles to the 128x128 program,
     # which attaches nothing, as the last case checks)

@@ -15,54 +15,58 @@ import torch
 
 from oracle import unet as ou
 
-F = int(os.environ.get("FRAMES", "14"))
-H, W = int(os.environ.get("LAT_H", "72")), int(os.environ.get("LAT_W", "128"))
-t0 = time.time()
-with torch.device("meta"):
-    o = ou.UNetSpatioTemporalConditionControlNetModel(ou.SVD_CONFIG)
-o = o.to_empty(device="cpu")
-with torch.no_grad():
-    for p in o.parameters():
-        if p.ndim >= 2:
-            p.normal_(0.0, 1.0 / p[0].numel() ** 0.5)
-        else:
-            p.fill_(0.0)
-    for m in o.modules():
-        if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)):
-            m.weight.fill_(1.0)
-print(f"model built in {time.time() - t0:.0f} s; threads {torch.get_num_threads()}, os.cpu_count {os.cpu_count()}", flush=True)
-t_start = [time.time()]
+
+def run_full_forward(F=14, H=72, W=128, verbose=True):
+    """builds the fp32 oracle UNet, runs ONE forward on the host cores, returns the result record"""
+    t0 = time.time()
+    with torch.device("meta"):
+        o = ou.UNetSpatioTemporalConditionControlNetModel(ou.SVD_CONFIG)
+    o = o.to_empty(device="cpu")
+    with torch.no_grad():
+        for p in o.parameters():
+            if p.ndim >= 2:
+                p.normal_(0.0, 1.0 / p[0].numel() ** 0.5)
+            else:
+                p.fill_(0.0)
+        for m in o.modules():
+            if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)):
+                m.weight.fill_(1.0)
+    out = sys.stderr if not verbose else sys.stdout
+    print(f"model built in {time.time() - t0:.0f} s; threads {torch.get_num_threads()}, os.cpu_count {os.cpu_count()}", file=out, flush=True)
+    t_start = [time.time()]
+
+    def hook(name):
+        def f(mod, inp, res):
+            print(f"  {name} done at {time.time() - t_start[0]:.0f} s", file=out, flush=True)
+        return f
+
+    for i, b in enumerate(o.down_blocks):
+        b.register_forward_hook(hook(f"down_blocks.{i}"))
+        for j, r in enumerate(b.resnets):
+            r.register_forward_hook(hook(f"down_blocks.{i}.resnets.{j}"))
+    o.mid_block.register_forward_hook(hook("mid_block"))
+    for i, b in enumerate(o.up_blocks):
+        b.register_forward_hook(hook(f"up_blocks.{i}"))
+        for j, r in enumerate(b.resnets):
+            r.register_forward_hook(hook(f"up_blocks.{i}.resnets.{j}"))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, F, 8, H, W, generator=g)
+    enc = torch.randn(2, 1, 1024, generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    t_start[0] = time.time()
+    with torch.no_grad():
+        y = o(x, torch.tensor(1.0), enc, added_time_ids=ids, return_dict=False)[0]
+    dt = time.time() - t_start[0]
+    tflop = 89.69 * (F / 14.0) * (H * W) / (72 * 128)          # algorithmic, SURVEY.md App. B (attention term scaled linearly: a bound)
+    return {"workload": f"one UNet forward, CFG batch 2 x {F} frames x {H}x{W} latent, real-width SVD UNet, fp32 oracle (torch eager)",
+            "seconds": round(dt, 1), "algorithmic_tflop": round(tflop, 2), "tflops": round(tflop / dt, 4),
+            "threads": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "finite": bool(torch.isfinite(y).all()),
+            "frames_per_s_c2_equivalent": round(14.0 / (25.0 * dt * (14.0 / F) * (72 * 128) / (H * W)), 6)}
 
 
-def hook(name):
-    def f(mod, inp, out):
-        print(f"  {name} done at {time.time() - t_start[0]:.0f} s", flush=True)
-    return f
-
-
-for i, b in enumerate(o.down_blocks):
-    b.register_forward_hook(hook(f"down_blocks.{i}"))
-    for j, r in enumerate(b.resnets):
-        r.register_forward_hook(hook(f"down_blocks.{i}.resnets.{j}"))
-o.mid_block.register_forward_hook(hook("mid_block"))
-for i, b in enumerate(o.up_blocks):
-    b.register_forward_hook(hook(f"up_blocks.{i}"))
-    for j, r in enumerate(b.resnets):
-        r.register_forward_hook(hook(f"up_blocks.{i}.resnets.{j}"))
-g = torch.Generator().manual_seed(1)
-x = torch.randn(2, F, 8, H, W, generator=g)
-enc = torch.randn(2, 1, 1024, generator=g)
-ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
-t_start[0] = time.time()
-with torch.no_grad():
-    y = o(x, torch.tensor(1.0), enc, added_time_ids=ids, return_dict=False)[0]
-dt = time.time() - t_start[0]
-tflop = 89.69 * (F / 14.0) * (H * W) / (72 * 128)          # algorithmic, SURVEY.md App. B (attention term scaled linearly: a bound)
-res = {"workload": f"one UNet forward, CFG batch 2 x {F} frames x {H}x{W} latent, real-width SVD UNet, fp32 oracle (torch eager)",
-       "seconds": round(dt, 1), "algorithmic_tflop": round(tflop, 2), "tflops": round(tflop / dt, 4),
-       "threads": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "finite": bool(torch.isfinite(y).all()),
-       "frames_per_s_c2_equivalent": round(14.0 / (25.0 * dt * (14.0 / F) * (72 * 128) / (H * W)), 6)}
-print(json.dumps(res), flush=True)
-os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-with open(os.path.join(REPO, "gpurun_out", "cpu_full_forward.json"), "w") as f:
-    json.dump(res, f, indent=1)
+if __name__ == "__main__":
+    res = run_full_forward(int(os.environ.get("FRAMES", "14")), int(os.environ.get("LAT_H", "72")), int(os.environ.get("LAT_W", "128")))
+    print(json.dumps(res), flush=True)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "cpu_full_forward.json"), "w") as f:
+        json.dump(res, f, indent=1)

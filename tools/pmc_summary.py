@@ -7,6 +7,14 @@ import sys
 from collections import defaultdict
 
 
+def kernels_sha16():
+    """the fingerprint bench.py recomputes (bench.kernels_sha16): which kernel sources these passes ran"""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.kernels_sha16()
+
+
 def load(path, counter):
     agg = defaultdict(lambda: [0, 0.0, 0.0])     # name -> [dispatches, counter sum, ns]
     with open(path) as f:
@@ -45,7 +53,8 @@ def main(fetch_csv, write_csv, json_out=None):
                "kernels": {k.split("(")[0]: {"launches": v[0], "fetch_mb": round(v[1] * 2048 / v[0] / 1e6, 2),
                                              "write_mb": round(wr.get(k, [0, 0.0, 0.0])[1] * 1024 / v[0] / 1e6, 2)}
                            for k, v in fam.items()},
-               "gemm_family_bytes_per_launch": int(total / max(launches, 1))}
+               "gemm_family_bytes_per_launch": int(total / max(launches, 1)),
+               "kernels_sha16": kernels_sha16()}
         with open(json_out, "w") as f:
             json.dump(doc, f, indent=1)
 
