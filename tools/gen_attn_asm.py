@@ -155,15 +155,27 @@ class Gen:
             def C(q):
                 return ("C", "v_cvt_pk_f16_f32 %s, %s, %s" % (v(p0 + q), v(s0 + 2 * q), v(s0 + 2 * q + 1)),
                         [("v", s0 + 2 * q), ("v", s0 + 2 * q + 1)], [("v", p0 + q)], 4)
-            for q in range(16):
-                fill += [E(2 * q), E(2 * q + 1)]
+            def A2(q):
+                if "pkadd" in OPT and q:      # experiment: one packed add per pair (v_pk_add_f32 beside MFMAs)
+                    return [("A", "v_pk_add_f32 %s, %s, %s" % (vr(PS0, 2), vr(PS0, 2), vr(s0 + 2 * q, 2)),
+                             R(PS0, 2) + R(s0 + 2 * q, 2), R(PS0, 2), 5)]
+                out = []
                 for r in (2 * q, 2 * q + 1):
                     ps = PS0 + (r & 1)
                     if q == 0:
-                        fill.append(("A", "v_add_f32_e32 %s, 0, %s" % (v(ps), v(s0 + r)), [("v", s0 + r)], [("v", ps)], 4))
+                        out.append(("A", "v_add_f32_e32 %s, 0, %s" % (v(ps), v(s0 + r)), [("v", s0 + r)], [("v", ps)], 4))
                     else:
-                        fill.append(("A", "v_add_f32_e32 %s, %s, %s" % (v(ps), v(ps), v(s0 + r)), [("v", ps), ("v", s0 + r)], [("v", ps)], 4))
-                fill.append(C(q))
+                        out.append(("A", "v_add_f32_e32 %s, %s, %s" % (v(ps), v(ps), v(s0 + r)), [("v", ps), ("v", s0 + r)], [("v", ps)], 4))
+                return out
+            if "pkadd" in OPT:                # the pair's sum and conversion run one pair behind its exponentials
+                for q in range(16):
+                    fill += [E(2 * q), E(2 * q + 1)]
+                    if q:
+                        fill += A2(q - 1) + [C(q - 1)]
+                fill += A2(15) + [C(15)]
+            else:
+                for q in range(16):
+                    fill += [E(2 * q), E(2 * q + 1)] + A2(q) + [C(q)]
         ngaps = max(len(mf), 1)
         fi = 0
         if not prefetched:

@@ -10,7 +10,7 @@ import csv, glob, collections
 for f in sorted(glob.glob("gpurun_out/attn_pmc/p*/*counter_collection.csv")):
     agg = collections.defaultdict(float); n = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
-        if "attn_spatial" in r["Kernel_Name"]:
+        if "attn_spatial" in r["Kernel_Name"] or "attn_pipe" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     for k in agg: print(f"{k:32s} {agg[k]/n[k]:16.0f}  (avg over {n[k]} launches)")
 PY
