@@ -126,6 +126,8 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)       # AttributeError here = header / library mismatch
             fn.restype, fn.argtypes = res, args
+        if os.environ.get("LKGD_ATTN_PIPE"):     # A/B measurements only (same-box bench pairs): 1 = never the software-pipelined
+            l.lkgd_debug_set_attn_pipe(int(os.environ["LKGD_ATTN_PIPE"]))   # attention program, 2 = wherever legal
         _lib = l
     return _lib
 
