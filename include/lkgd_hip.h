@@ -162,6 +162,21 @@ int lkgd_layernorm(const void* x, int32_t ldx, int64_t T, int32_t C, const float
                    int32_t rb_md, void* out, int32_t ldo, lkgd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * 3b. LayerNorm + GEGLU feed-forward + output projection + residual(s) in one launch, C = 320 / inner 1280 (the 72x128
+ *    level).  x' = x + rowbias[idx(row)] (idx = (row / rb_d1) % rb_md; rowbias may be NULL);
+ *        out = s_acc * ( W2 . ( hidden * gelu(gate) ) + b2 + x' ) + r2 * res2,   [hidden | gate] = W1 . LN(x') + b1
+ *    LN without affine (gamma / beta folded into W1 / b1 when the stream is packed), exact-erf GELU, fp32 accumulation, fp16
+ *    in / out.  wstream: the chunk stream lkgd_amd/packing.py::pack_ff_fused builds (W1, b1, W2 in the order the kernel's
+ *    generated loop consumes them, 2 539 520 bytes).  The [T, 1280] intermediate is never written.
+ *    Replaces: BasicTransformerBlock `norm3 -> ff` + residual (patch/patch.py:551-580) and TemporalBasicTransformerBlock
+ *    `norm_in -> ff_in` + residual / `norm3 -> ff` + residual + AlphaBlender (patch/patch.py:599-608, :670-680; [EXT]
+ *    diffusers FeedForward / GEGLU).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_ff_fused_c320(const void* x, int32_t ldx, int64_t T, const void* rowbias, int32_t ldrb, int32_t rb_d1, int32_t rb_md,
+                       const void* wstream, const float* b2, float eps, float s_acc, const void* res2, int32_t ldr2, float r2,
+                       void* out, int32_t ldo, lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * 4. Spatial self-attention, head_dim 64, flash-style (online softmax, scores never materialised).
  *    q/k/v: fp16 token matrices; head h occupies columns [h*64, h*64+64) of each; batch entry n owns rows
  *    [n*S, (n+1)*S).  kv_batch_map (int32[nbatch], may be NULL = identity) selects which batch entry's K/V rows a

@@ -270,6 +270,29 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     return out
 
 
+#: A/B switch of the one-launch feed-forward of the 72x128 level (False = LayerNorm + GEGLU GEMM + FF-out GEMM)
+FF_FUSED = os.environ.get("LKGD_NO_FF_FUSED", "0") != "1"
+
+
+def ff_fused_ok(C_: int, inner: int) -> bool:
+    return FF_FUSED and C_ == 320 and inner == 1280
+
+
+def ff_fused(x: torch.Tensor, wstream: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, eps: float = 1e-5,
+             rowbias: Optional[torch.Tensor] = None, rowmap: Optional[RowMap] = None, s_acc: float = 1.0,
+             res2: Optional[torch.Tensor] = None, r2: float = 0.0) -> torch.Tensor:
+    """out = s_acc * (FF(LN(x')) + x') + r2 * res2 with x' = x + rowbias[(row // d1) % md]  (lkgd_ff_fused_c320)"""
+    _req(x, torch.float16, "x"); _req(wstream, torch.float16, "wstream"); _req(b2, torch.float32, "b2")
+    d1, m1, d2, md = (rowmap if rowmap is not None else (1, 1, 1, 1))[:4]
+    if rowbias is not None and (m1 != 1 or d2 != 1):
+        raise _lib.LkgdHipError("ff_fused: only (row // d1) % md row maps")
+    check(_L().lkgd_ff_fused_c320(x.data_ptr(), _ld(x), x.shape[0], _ptr(rowbias), _ld(rowbias) if rowbias is not None else 0,
+                                  d1, min(md, 1 << 30), wstream.data_ptr(), b2.data_ptr(), eps, s_acc, _ptr(res2),
+                                  _ld(res2) if res2 is not None else 0, r2, out.data_ptr(), _ld(out), _stream()),
+          "lkgd_ff_fused_c320")
+    return out
+
+
 def attn_spatial(q, k, v, out, nbatch: int, S: int, heads: int, kv_batch_map: Optional[torch.Tensor] = None,
                  scale: float = 0.125, Sq: Optional[int] = None):
     """S = key / value rows per batch entry; Sq = query rows (defaults to S; smaller on a frame-sharded DiT rank)"""

@@ -70,3 +70,45 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor, half: int = None):
         half = geglu_half(w.shape[0], w.shape[1])
     perm = geglu_perm(inner, half, w.device)
     return w[perm].to(torch.float16).contiguous(), b[perm].to(torch.float32).contiguous(), half
+
+
+def pack_ff_fused(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """Chunk stream of lkgd_ff_fused_c320 (lkgd_amd/csrc/ff_fused.hip, tools/gen_ff_asm.py) for a GEGLU feed-forward
+    320 -> 2 x 1280 -> 320.  w1 [2560, 320] / b1 [2560] fp32: the GEGLU projection in diffusers' row order (hidden rows
+    0..1279, gate rows 1280..2559) with the LayerNorm affine already folded in; w2 [320, 1280].  Returns fp16 [n] = 120 chunks:
+        unit u = 64 hidden channels, tile f = 32 of them:  c0 W1 hidden f0 | c1 W1 gate f0 | c2 W2 f1 of unit u-1 (u > 0) |
+        c3 W1 hidden f1 | c4 W1 gate f1 | c5 W2 f0; after unit 19 the stream ends with W2 f1 of unit 19.
+    W1 chunk = 21 MFMA A fragments of 64 lanes x 8 halfs (lane = 32 h + row): fragment 0 carries the bias as (b_hi, b_lo) in
+    k-slots 0, 1 of the h = 0 lanes (multiplied by ones in the kernel: b_hi + b_lo restores fp32 to 2^-22), fragments 1..20
+    W1[base + row][16 ks + 8 h + e].  W2 chunk = 20 fragments (k-step ss, output tile ti): W2[32 ti + row][64 u + 32 f + 16 ss +
+    (e & 3) + 8 (e >> 2) + 4 h] - the k-slot order in which the first product's accumulators hold the hidden channels."""
+    assert w1.shape == (2560, 320) and b1.shape == (2560,) and w2.shape == (320, 1280)
+    dev = w1.device
+    w1h = w1.to(torch.float16).reshape(2, 20, 2, 32, 20, 2, 8)            # [type, u, f, row, ks, h, e]
+    b1f = b1.to(torch.float32).reshape(2, 20, 2, 32)
+    b_hi = b1f.to(torch.float16)
+    b_lo = (b1f - b_hi.to(torch.float32)).to(torch.float16)
+    h_, e_ = torch.arange(2, device=dev)[:, None], torch.arange(8, device=dev)[None, :]
+    kidx = (e_ & 3) + 8 * (e_ >> 2) + 4 * h_                               # [h, e] -> position inside a 16-channel k-step
+    w2h = w2.to(torch.float16).reshape(10, 32, 20, 2, 2, 16)               # [ti, row, u, f, ss, k16]
+
+    def w1_chunk(t, u, f):
+        bias = torch.zeros(2, 32, 8, dtype=torch.float16, device=dev)
+        bias[0, :, 0], bias[0, :, 1] = b_hi[t, u, f], b_lo[t, u, f]
+        body = w1h[t, u, f].permute(1, 2, 0, 3)                             # [ks, h, row, e]
+        return torch.cat([bias.reshape(1, -1), body.reshape(20, -1)]).reshape(-1)
+
+    def w2_chunk(u, f):
+        blk = w2h[:, :, u, f][..., kidx]                                    # [ti, row, ss, h, e]
+        return blk.permute(2, 0, 3, 1, 4).reshape(-1)                       # [ss, ti, h, row, e]
+
+    chunks = []
+    for u in range(20):
+        chunks += [w1_chunk(0, u, 0), w1_chunk(1, u, 0)]
+        if u:
+            chunks.append(w2_chunk(u - 1, 1))
+        chunks += [w1_chunk(0, u, 1), w1_chunk(1, u, 1), w2_chunk(u, 0)]
+    chunks.append(w2_chunk(19, 1))
+    out = torch.cat(chunks).contiguous()
+    assert out.numel() * 2 == 80 * 21504 + 40 * 20480
+    return out
