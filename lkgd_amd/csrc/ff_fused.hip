@@ -47,6 +47,9 @@ struct ff_params {
   int npanels;
 };
 
+// PE: a row-indexed bias is added to x before the LayerNorm (and is part of the residual): ff_in.  R2: a second residual
+// (the AlphaBlender form of the temporal block's last feed-forward).
+template <bool PE, bool R2>
 __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(256))) void ff_fused_kernel(ff_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -79,57 +82,77 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
   const unsigned vob = 20480u + lane * 16;
   const unsigned hmask = h == 0 ? 0xffffffffu : 0u;
 
-#pragma unroll 1
-  for (int panel = blockIdx.x; panel < p.npanels; panel += gridDim.x) {
-    // ---- the wave's 32 token rows: this lane holds channels 16 ks + 8 h + 0..7 of row `tok` (the B operand layout)
+  // the wave's 32 token rows of a panel: this lane holds channels 16 ks + 8 h + 0..7 of its row (the B operand layout)
+  auto load_rows = [&](int panel, half8_t (&raw)[20], half8_t (&pv)[20], bool bias_only) {
     const long long tok = (long long)panel * (FF_WAVES * 32) + w * 32 + l31;
     const long long tokc = tok < p.T ? tok : p.T - 1;
-    {
-      const half_t* xp = p.x + tokc * p.ldx + 8 * h;
-      const half_t* pe = p.rowbias ? p.rowbias + (long long)((tokc / p.rb_d1) % p.rb_md) * p.ldrb + 8 * h : nullptr;
-      // two passes over the fp16 rows kept in registers (80 + 80 with a row bias): sums, then normalise + pack
-      half8_t raw[20], pv[20];
-      float s = 0.f, q = 0.f;
+    const half_t* xp = p.x + tokc * p.ldx + 8 * h;
+    const half_t* pe = PE ? p.rowbias + (long long)((tokc / p.rb_d1) % p.rb_md) * p.ldrb + 8 * h : nullptr;
 #pragma unroll
-      for (int ks = 0; ks < 20; ++ks) {
+    for (int ks = 0; ks < 20; ++ks) {
+      if (!bias_only) {
+#ifdef FF_X_NOPRO      /* timing knob (tools/micro/ff_knobs.sh): no token loads */
+        raw[ks] = (half8_t){1, 2, 3, 4, 5, 6, 7, (half_t)ks};
+#else
         raw[ks] = *(const half8_t*)(xp + 16 * ks);
-        if (pe) pv[ks] = *(const half8_t*)(pe + 16 * ks);
+#endif
       }
-#pragma unroll
-      for (int ks = 0; ks < 20; ++ks) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = (float)raw[ks][e];
-          if (pe) f += (float)pv[ks][e];
-          s += f;
-          q += f * f;
-        }
-      }
-      s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 32, 64);
-      const float mean = s * (1.0f / FF_C);
-      float var = q * (1.0f / FF_C) - mean * mean;
-      var = var < 0.f ? 0.f : var;
-      const float rstd = __builtin_amdgcn_rsqf(var + p.eps);
-      const float nm = -mean * rstd;
-      ff_for20([&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-        half8_t z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = (float)raw[ks][e];
-          if (pe) f += (float)pv[ks][e];
-          z[e] = (half_t)fmaf(f, rstd, nm);
-        }
-        typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
-        const uint4_t u = __builtin_bit_cast(uint4_t, z);
-        ff_agpr_write<FF_ZF + 4 * ks + 0>(u[0]);
-        ff_agpr_write<FF_ZF + 4 * ks + 1>(u[1]);
-        ff_agpr_write<FF_ZF + 4 * ks + 2>(u[2]);
-        ff_agpr_write<FF_ZF + 4 * ks + 3>(u[3]);
-      });
+      if (PE && (bias_only || !PE)) pv[ks] = *(const half8_t*)(pe + 16 * ks);
     }
+  };
+  // LayerNorm of x' = x (+ row bias) in registers -> fp16 MFMA operands a[160:239]; returns mean and sigma of the row
+  auto layernorm_rows = [&](half8_t (&raw)[20], half8_t (&pv)[20], float& ln_mean, float& ln_sigma) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 20; ++ks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)raw[ks][e];
+        if (PE) f += (float)pv[ks][e];
+        s += f;
+        q += f * f;
+      }
+    }
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float mean = s * (1.0f / FF_C);
+    float var = q * (1.0f / FF_C) - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = __builtin_amdgcn_rsqf(var + p.eps);
+    const float nm = -mean * rstd;
+    ln_mean = mean;
+    ln_sigma = (var + p.eps) * rstd;
+    ff_for20([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      // (opaque copies: the second pass converts the fp16 rows AGAIN instead of keeping 160 fp32 values of the first
+      // pass alive - those would not fit the vector registers and the compiler would park them in accumulation registers)
+      asm volatile("" : "+v"(raw[ks]));
+      if (PE) asm volatile("" : "+v"(pv[ks]));
+      half8_t z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)raw[ks][e];
+        if (PE) f += (float)pv[ks][e];
+        z[e] = (half_t)fmaf(f, rstd, nm);
+      }
+      typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+      const uint4_t u = __builtin_bit_cast(uint4_t, z);
+      ff_agpr_write<FF_ZF + 4 * ks + 0>(u[0]);
+      ff_agpr_write<FF_ZF + 4 * ks + 1>(u[1]);
+      ff_agpr_write<FF_ZF + 4 * ks + 2>(u[2]);
+      ff_agpr_write<FF_ZF + 4 * ks + 3>(u[3]);
+    });
+  };
 
+  float ln_mean, ln_sigma;        // the epilogue rebuilds the residual x' = z * sigma + mean from the normalised fragments
+  {
+    half8_t raw[20], pv[20];
+    load_rows(blockIdx.x, raw, pv, false);
+    if (PE) load_rows(blockIdx.x, raw, pv, true);
+    layernorm_rows(raw, pv, ln_mean, ln_sigma);
+  }
+#pragma unroll 1
+  for (int panel = blockIdx.x; panel < p.npanels; panel += gridDim.x) {
     asm volatile(FF_PANEL_ASM
                  : [splo] "+s"(splo), [sphi] "+s"(sphi)
                  : [fa0] "v"(fa0), [fa1] "v"(fa1), [fa2] "v"(fa2), [vo0] "v"(vo0), [vo1] "v"(vo1), [vo2] "v"(vo2), [vo3] "v"(vo3),
@@ -137,45 +160,86 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
                    [sp0hi] "s"(sp0hi)
                  : FF_CLOBBERS);
 
-    // ---- epilogue: lane owns token row `tok`; accumulator r of output tile i is channel 32 i + (r & 3) + 8 (r >> 2) + 4 h
+    // ---- the NEXT panel's token rows start their way from memory now: they land under this panel's epilogue
+    const int nextp = panel + (int)gridDim.x;
+    half8_t nraw[20], npv[20];
+    if (nextp < p.npanels) load_rows(nextp, nraw, npv, false);
+
+    // ---- epilogue: lane (token, h) owns accumulator r of output tile i = channel 32 i + (r & 3) + 8 (r >> 2) + 4 h.  The
+    //      residual x' is rebuilt from the normalised fragments still in a[160:239] (x' = z sigma + mean: one more fp16
+    //      rounding of x' - mean, the size of x's own), which lane (token, h') holds for channels 16 ks + 8 h' + 0..7: after
+    //      one half-wave exchange per dword pair - lanes 0..31 give away channels 4..7 and take the partner's 8..11 - a lane
+    //      holds exactly its epilogue channels.  The same exchange on the OUTPUT pairs the two 4-channel groups of a k-step
+    //      into 8 consecutive channels per lane: lanes 0..31 store channels 16 ks + 0..7, lanes 32..63 16 ks + 8..15, 16 bytes.
     int lane2;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane2));
     const int h2 = lane2 >> 5, l2 = lane2 & 31;
     const long long tok2 = (long long)panel * (FF_WAVES * 32) + w * 32 + l2;
     const long long tok2c = tok2 < p.T ? tok2 : p.T - 1;
     const bool live = tok2 < p.T;
-    const half_t* xr = p.x + tok2c * p.ldx + 4 * h2;
-    const half_t* per = p.rowbias ? p.rowbias + (long long)((tok2c / p.rb_d1) % p.rb_md) * p.ldrb + 4 * h2 : nullptr;
-    const half_t* r2p = p.res2 ? p.res2 + tok2c * p.ldr2 + 4 * h2 : nullptr;
+    const half_t* r2p = R2 ? p.res2 + tok2c * p.ldr2 + 8 * h2 : nullptr;
     const float* b2p = p.b2 + 4 * h2;
-    half_t* op = p.out + tok2c * p.ldo + 4 * h2;
+    half_t* op = p.out + tok2c * p.ldo + 8 * h2;
     const float sa = p.s_acc, r2 = p.r2;
-    ff_for10([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      ff_for4([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        constexpr int c0 = 32 * i + 8 * g;
+#ifdef FF_X_NOEPI       /* timing knob: no epilogue (one accumulator read keeps the statement alive) */
+    if (live && ff_agpr_read<FF_YACC>() == 12345.678f) *op = (half_t)1.f;
+    if (false)
+#endif
+    ff_for20([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      constexpr int i = ks >> 1, g0 = 2 * (ks & 1);            // output tile, first of the k-step's two 4-channel groups
+      // (a scheduling fence per k-step: without it the compiler hoists all forty bias loads, runs out of vector registers
+      // and parks values in ACCUMULATION registers - the ones that still hold Y^T and z^T here)
+      asm volatile("" ::: "memory");
+      unsigned z[4];
+      z[0] = __builtin_bit_cast(unsigned, ff_agpr_read<FF_ZF + 4 * ks + 0>());
+      z[1] = __builtin_bit_cast(unsigned, ff_agpr_read<FF_ZF + 4 * ks + 1>());
+      z[2] = __builtin_bit_cast(unsigned, ff_agpr_read<FF_ZF + 4 * ks + 2>());
+      z[3] = __builtin_bit_cast(unsigned, ff_agpr_read<FF_ZF + 4 * ks + 3>());
+      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(z[0]), "+v"(z[2]));
+      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(z[1]), "+v"(z[3]));
+      unsigned rr[4];
+      if (R2) {        // the second residual: 16 bytes of the lane's STORE group, exchanged back into the accumulator layout
+        typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+        const uint4_t rv = *(const uint4_t*)(r2p + 16 * ks);
+        rr[0] = rv[0]; rr[1] = rv[1]; rr[2] = rv[2]; rr[3] = rv[3];
+        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(rr[0]), "+v"(rr[2]));
+        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(rr[1]), "+v"(rr[3]));
+      }
+      unsigned o[4];
+      ff_static_for([&](auto jc) {
+        constexpr int j = decltype(jc)::value;                  // group g0 + j: channels 32 i + 8 (g0 + j) + 4 h + 0..3
+        constexpr int c0 = 32 * i + 8 * (g0 + j);
         const float4_t bb = *(const float4_t*)(b2p + c0);
-        const half4_t xv = *(const half4_t*)(xr + c0);
         float4_t y;
-        y[0] = ff_agpr_read<FF_YACC + 16 * i + 4 * g + 0>();
-        y[1] = ff_agpr_read<FF_YACC + 16 * i + 4 * g + 1>();
-        y[2] = ff_agpr_read<FF_YACC + 16 * i + 4 * g + 2>();
-        y[3] = ff_agpr_read<FF_YACC + 16 * i + 4 * g + 3>();
-        float4_t xs = {(float)xv[0], (float)xv[1], (float)xv[2], (float)xv[3]};
-        if (per) {
-          const half4_t pv = *(const half4_t*)(per + c0);
-          xs += (float4_t){(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
+        y[0] = ff_agpr_read<FF_YACC + 16 * i + 4 * (g0 + j) + 0>();
+        y[1] = ff_agpr_read<FF_YACC + 16 * i + 4 * (g0 + j) + 1>();
+        y[2] = ff_agpr_read<FF_YACC + 16 * i + 4 * (g0 + j) + 2>();
+        y[3] = ff_agpr_read<FF_YACC + 16 * i + 4 * (g0 + j) + 3>();
+        const half2_t z0 = __builtin_bit_cast(half2_t, z[2 * j]), z1 = __builtin_bit_cast(half2_t, z[2 * j + 1]);
+        const float4_t xs = {fmaf((float)z0[0], ln_sigma, ln_mean), fmaf((float)z0[1], ln_sigma, ln_mean),
+                             fmaf((float)z1[0], ln_sigma, ln_mean), fmaf((float)z1[1], ln_sigma, ln_mean)};
+        float4_t ov = (y + bb + xs) * sa;
+        if (R2) {
+          const half2_t q0 = __builtin_bit_cast(half2_t, rr[2 * j]), q1 = __builtin_bit_cast(half2_t, rr[2 * j + 1]);
+          ov += (float4_t){(float)q0[0], (float)q0[1], (float)q1[0], (float)q1[1]} * r2;
         }
-        float4_t o = (y + bb + xs) * sa;
-        if (r2p) {
-          const half4_t rv = *(const half4_t*)(r2p + c0);
-          o += (float4_t){(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]} * r2;
-        }
-        const half4_t ov = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-        if (live) *(half4_t*)(op + c0) = ov;
-      });
+        const half2_t a = {(half_t)ov[0], (half_t)ov[1]}, bq = {(half_t)ov[2], (half_t)ov[3]};
+        o[2 * j] = __builtin_bit_cast(unsigned, a);
+        o[2 * j + 1] = __builtin_bit_cast(unsigned, bq);
+      }, FfIC<0>{}, FfIC<1>{});
+      // lanes 0..31 (channels 0..3 | 8..11 of the k-step) give away 8..11 and take the partner's 4..7; lanes 32..63 hold
+      // 8..15 afterwards: both halves have their eight channels in order
+      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(o[0]), "+v"(o[2]));
+      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(o[1]), "+v"(o[3]));
+      typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+      if (live) *(uint4_t*)(op + 16 * ks) = (uint4_t){o[0], o[1], o[2], o[3]};
     });
+
+    if (nextp < p.npanels) {
+      if (PE) load_rows(nextp, nraw, npv, true);        // (the small row-bias table: L2-resident, loaded late to save registers)
+      layernorm_rows(nraw, npv, ln_mean, ln_sigma);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the chunks issued ahead for a panel that does not come
 }
@@ -185,12 +249,15 @@ extern "C" int lkgd_ff_fused_c320(const void* x, int32_t ldx, int64_t T, const v
                                   int32_t ldr2, float r2, void* out, int32_t ldo, lkgd_stream_t stream) {
   if (!x || !wstream || !b2 || !out) return LKGD_E_NULL;
   if (T <= 0 || T > 0x7fffffffLL * 64) return LKGD_E_SHAPE;
-  if (ldx % 8 || ldo % 4 || ldx < FF_C || ldo < FF_C) return LKGD_E_ALIGN;
-  if (!aligned16(x) || !aligned16(wstream) || ((uintptr_t)out & 7) || !aligned16(b2)) return LKGD_E_ALIGN;
+  if (ldx % 8 || ldo % 8 || ldx < FF_C || ldo < FF_C) return LKGD_E_ALIGN;
+  if (!aligned16(x) || !aligned16(wstream) || !aligned16(out) || !aligned16(b2)) return LKGD_E_ALIGN;
   if (rowbias && (ldrb % 8 || ldrb < FF_C || rb_d1 <= 0 || rb_md <= 0 || !aligned16(rowbias))) return LKGD_E_SHAPE;
-  if (res2 && (ldr2 % 4 || ldr2 < FF_C || ((uintptr_t)res2 & 7))) return LKGD_E_ALIGN;
+  if (res2 && (ldr2 % 8 || ldr2 < FF_C || !aligned16(res2))) return LKGD_E_ALIGN;
   LKGD_DEVICE_ONCE_BEGIN
-    if (hipFuncSetAttribute((const void*)ff_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)ff_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)ff_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)ff_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)ff_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess)
       return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
   int dev = 0, cus = 256;
@@ -204,6 +271,11 @@ extern "C" int lkgd_ff_fused_c320(const void* x, int32_t ldx, int64_t T, const v
   p.wstream = (const char*)wstream; p.b2 = b2; p.eps = eps; p.s_acc = s_acc; p.r2 = r2;
   p.res2 = (const half_t*)res2; p.ldr2 = ldr2; p.out = (half_t*)out; p.ldo = ldo; p.npanels = (int)npanels;
   const int grid = npanels < cus ? (int)npanels : cus;
-  hipLaunchKernelGGL(ff_fused_kernel, dim3(grid), dim3(FF_WAVES * 64), FF_LDS, (hipStream_t)stream, p);
+  const dim3 gr(grid), bl(FF_WAVES * 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (rowbias && res2) hipLaunchKernelGGL((ff_fused_kernel<true, true>), gr, bl, FF_LDS, st, p);
+  else if (rowbias) hipLaunchKernelGGL((ff_fused_kernel<true, false>), gr, bl, FF_LDS, st, p);
+  else if (res2) hipLaunchKernelGGL((ff_fused_kernel<false, true>), gr, bl, FF_LDS, st, p);
+  else hipLaunchKernelGGL((ff_fused_kernel<false, false>), gr, bl, FF_LDS, st, p);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }

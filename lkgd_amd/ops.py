@@ -286,10 +286,17 @@ def ff_fused(x: torch.Tensor, wstream: torch.Tensor, b2: torch.Tensor, out: torc
     d1, m1, d2, md = (rowmap if rowmap is not None else (1, 1, 1, 1))[:4]
     if rowbias is not None and (m1 != 1 or d2 != 1):
         raise _lib.LkgdHipError("ff_fused: only (row // d1) % md row maps")
+    ev = GEMM_EVENTS        # a GEMM-family launch for bench.py's roofline line: 2 T (2560 x 320 + 320 x 1280) algorithmic FLOP
+    if ev is not None:
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
     check(_L().lkgd_ff_fused_c320(x.data_ptr(), _ld(x), x.shape[0], _ptr(rowbias), _ld(rowbias) if rowbias is not None else 0,
                                   d1, min(md, 1 << 30), wstream.data_ptr(), b2.data_ptr(), eps, s_acc, _ptr(res2),
                                   _ld(res2) if res2 is not None else 0, r2, out.data_ptr(), _ld(out), _stream()),
           "lkgd_ff_fused_c320")
+    if ev is not None:
+        e_ev.record()
+        ev.append((s_ev, e_ev, 2.0 * x.shape[0] * (2560 * 320 + 320 * 1280)))
     return out
 
 

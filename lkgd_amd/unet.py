@@ -36,7 +36,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import LkgdHipError
-from .packing import pack_conv3x3, pack_conv3x3_c8, pack_geglu, pack_linear, pack_tconv3
+from .packing import pack_conv3x3, pack_conv3x3_c8, pack_ff_fused, pack_geglu, pack_linear, pack_tconv3
 
 #: row order of the temporal cross-attention context, see SURVEY.md App. C11.  "interleaved_0_27" reproduces
 #: diffusers 0.27.x (rows (pixel, batch)-ordered against (batch, pixel)-ordered hidden rows); "batch_major" = later.
@@ -303,8 +303,13 @@ class FeedForward(nn.Module):
         if norm is not None:
             w, b = _fold_ln(norm, w, b)
         wp, bp, half = pack_geglu(w, b)
-        return SimpleNamespace(wp=wp, bp=bp, half=half, wo=pack_linear(self.net[2].weight),
-                               bo=_f32(self.net[2].bias))
+        pk = SimpleNamespace(wp=wp, bp=bp, half=half, wo=pack_linear(self.net[2].weight), bo=_f32(self.net[2].bias),
+                             wfused=None)
+        w2 = self.net[2].weight.detach()
+        if norm is not None and ops.ff_fused_ok(w.shape[1], w2.shape[1]) and w2.shape[0] == w.shape[1]:
+            # the 72x128 level: LayerNorm + GEGLU + FF-out + residual(s) in one launch (lkgd_ff_fused_c320)
+            pk.wfused = pack_ff_fused(w.float(), b.float(), w2.float())
+        return pk
 
 
 def _fold_ln(norm: nn.LayerNorm, w: torch.Tensor, b: Optional[torch.Tensor]):
@@ -314,6 +319,20 @@ def _fold_ln(norm: nn.LayerNorm, w: torch.Tensor, b: Optional[torch.Tensor]):
     w32 = w.detach().float()
     b32 = w32 @ be + (b.detach().float() if b is not None else 0.0)
     return w32 * g[None, :], b32
+
+
+def _ff_ln(ctx: Ctx, pk, x: torch.Tensor, rowbias=None, rowmap=None, s_acc: float = 1.0, res2=None, r2: float = 0.0):
+    """s_acc * (FF(LN(x')) + x') + r2 * res2 with x' = x + rowbias[rowmap(row)]: norm3 -> ff / norm_in -> ff_in with their
+    residuals.  One launch where the fused kernel exists (C = 320), LayerNorm + two GEMMs elsewhere."""
+    if getattr(pk, "wfused", None) is not None and ops.FF_FUSED:
+        return ops.ff_fused(x, pk.wfused, pk.bo, ctx.new(x.shape[0], x.shape[1]), 1e-5, rowbias, rowmap, s_acc, res2, r2)
+    ln = ops.layernorm(x, None, None, 1e-5, rowbias=rowbias, rowmap=rowmap)
+    ep = dict(res1=x, r1=s_acc, s_acc=s_acc)
+    if rowbias is not None:
+        ep.update(rowbias=rowbias, rowmap=rowmap)
+    if res2 is not None:
+        ep.update(res2=res2, r2=r2)
+    return _ff(ctx, pk, ln, **ep)
 
 
 def _ff(ctx: Ctx, pk, x_norm: torch.Tensor, **epilogue) -> torch.Tensor:
@@ -422,8 +441,7 @@ class BasicTransformerBlock(nn.Module):
         """(literal attn2 for a multi-token context,) norm3 + feed-forward + residual"""
         if ctx.cross_Lk > 1:
             h1 = _cross_literal(self, ctx, h1, ops.rowmap_div(ctx.F * ctx.HW), ctx.b0)
-        ln3 = ops.layernorm(h1, None, None, 1e-5)
-        return _ff(ctx, self._pk.ff, ln3, res1=h1)
+        return _ff_ln(ctx, self._pk.ff, h1)
 
     def _joint(self, ctx: Ctx, ln: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
         """joint attention attn1n with the partner batch entry's K/V (patch/patch.py:438-501); the post step
@@ -528,8 +546,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         """h_s: output of the spatial block; returns alpha*h_s + (1-alpha)*temporal(h_s + posemb[f])"""
         pk, T, Cc = self._pk, h_s.shape[0], h_s.shape[1]
         fmap = ops.rowmap_div_mod(ctx.HW, ctx.F)
-        lnin = ops.layernorm(h_s, None, None, 1e-5, rowbias=posemb, rowmap=fmap)
-        m1 = _ff(ctx, pk.ffin, lnin, res1=h_s, rowbias=posemb, rowmap=fmap)        # ff_in(norm_in(m0)) + m0
+        m1 = _ff_ln(ctx, pk.ffin, h_s, rowbias=posemb, rowmap=fmap)               # ff_in(norm_in(m0)) + m0, m0 = h_s + pos
         att = ctx.new(T, Cc)
         va = None
         # LayerNorm + QKV + attention over the frames in one kernel where it exists (C = 320: the 72x128 level); the joint
@@ -610,9 +627,8 @@ class TemporalBasicTransformerBlock(nn.Module):
             m2 = self._joint(ctx, ln1, m2)
         if ctx.cross_Lk > 1:                  # literal attn2 over the time context (same row -> context map as the folded bias)
             m2 = _cross_literal(self, ctx, m2, xmap, ctx.b0 if order == "batch_major" else 0)
-        ln3 = ops.layernorm(m2, None, None, 1e-5)
         # ff(norm3(m2)) + m2, then AlphaBlender with the spatial branch - one epilogue
-        return _ff(ctx, pk.ff, ln3, s_acc=1.0 - alpha, res1=m2, r1=1.0 - alpha, res2=h_s, r2=alpha)
+        return _ff_ln(ctx, pk.ff, m2, s_acc=1.0 - alpha, res2=h_s, r2=alpha)
 
     def _joint(self, ctx: Ctx, ln1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
         """temporal joint branch (patch/patch.py:616-658): attn1n over the partner batch entry's frames"""

@@ -263,6 +263,40 @@ def test_resident_weight_kernel_has_no_register_spills():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("src,kernel,agprs", [("ff_fused.hip", "ff_fused_kernel", 244), ("attn_spatial_pipe.hip", "attn_pipe_kernel", 108)])
+def test_generated_loop_kernels_keep_their_accumulation_registers(src, kernel, agprs, tmp_path):
+    """ff_fused.hip / attn_spatial_pipe.hip keep state in accumulation registers ACROSS their asm statements (Y^T and z^T; Q and
+    O), which the compiler knows nothing about: it must never place values of its own there.  Checked on the ISA: every
+    instantiation allocates exactly the accumulation registers the generated loop names, has no scratch spills, and no
+    compiler-generated instruction (outside the #ASMSTART / #ASMEND blocks) touches an accumulation register."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    out = tmp_path / "k.o"
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm", "-mllvm",
+                        "-amdgpu-spill-vgpr-to-agpr=0", "--save-temps=obj", "-c", os.path.join(REPO, "lkgd_amd", "csrc", src),
+                        "-o", str(out)], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    isa = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
+    assert len(isa) == 1
+    text = open(tmp_path / isa[0]).read()
+    assert kernel in text
+    counts = [int(v) for v in re.findall(r"; NumAgprs: (\d+)", text)]
+    scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
+    assert counts and all(c == agprs for c in counts), counts
+    assert all(s == 0 for s in scratch), scratch
+    inside, bad = False, []
+    for line in text.splitlines():
+        if "#ASMSTART" in line:
+            inside = True
+        elif "#ASMEND" in line:
+            inside = False
+        elif not inside and not line.lstrip().startswith((";", ".")) and re.search(r"\ba(\d+|\[\d+:\d+\])", line.split(";")[0]):
+            bad.append(line.strip())
+    assert not bad, bad[:10]
+
+
 def test_clip_module_takes_transformers_state_dict_names(tmp_path):
     """lkgd_amd.clip keeps transformers' parameter names (image_encoder/ checkpoints load as they are), round-trips through
     save_pretrained / from_pretrained, ignores the persisted position_ids of older checkpoints, and refuses to run off the GPU"""

@@ -421,7 +421,23 @@ class Gen:
         assert nerr == 0, "%d problems" % nerr
 
     def text(self):
-        return " \\\n  ".join('"' + i.text + NL + '"' for i in self.ins if i.kind != "comment")
+        knob = os.environ.get("FF_GEN_KNOB", "").split("+")      # timing experiments only (tools/micro/ff_knobs.sh): results WRONG
+        keep = []
+        for i in self.ins:
+            if i.kind == "comment":
+                continue
+            if "nolds" in knob and i.kind in ("lds", "waitlgkm"):
+                continue
+            if "novalu" in knob and i.kind in ("valu", "trans") and "cost" in i.meta:
+                continue
+            if "nomfma" in knob and i.kind == "mfma":
+                continue
+            if "nodma" in knob and i.kind == "vmem":
+                continue
+            if "nobar" in knob and i.kind in ("barrier", "waitvm", "vmem"):
+                continue
+            keep.append(i)
+        return " \\\n  ".join('"' + i.text + NL + '"' for i in keep)
 
     def stats(self):
         cost = {"mfma": 8, "trans": 8, "valu": 4, "salu": 4, "lds": 4, "vmem": 4, "waitlgkm": 4, "waitvm": 4, "barrier": 4}
