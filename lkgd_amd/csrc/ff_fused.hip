@@ -13,7 +13,8 @@
 
 #define FF_WAVES 4
 #define FF_C 320
-#define FF_LDS (FF_NSLOT * FF_SLOT)
+#define FF_B2_OFF (FF_NSLOT * FF_SLOT)       // the output bias, 320 floats behind the ring
+#define FF_LDS (FF_B2_OFF + FF_C * 4)
 
 template <int REG>
 __device__ __forceinline__ float ff_agpr_read() {
@@ -24,6 +25,13 @@ __device__ __forceinline__ float ff_agpr_read() {
 template <int REG>
 __device__ __forceinline__ void ff_agpr_write(unsigned v) {
   asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(v), "i"(REG));
+}
+// v_permlane32_swap_b32: lanes 32..63 of `a` <-> lanes 0..31 of `b`.  Through the builtin, not inline asm: the instruction has
+// wait-state requirements after a VALU write of its operands that only the compiler's hazard recogniser sees
+__device__ __forceinline__ void ff_swap32(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
 }
 template <int V> struct FfIC { static constexpr int value = V; };
 template <class F, int... Is> __device__ __forceinline__ void ff_static_for(F&& f, FfIC<Is>...) { (f(FfIC<Is>{}), ...); }
@@ -66,6 +74,9 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
     for (int j = 0; j < 5; ++j) glds16(src + (w + 4 * j) * 1024, dst + (w + 4 * j) * 1024);
     glds16(src + 20480, dst + 20480);
   }
+  // the output bias goes to LDS once: the epilogue then needs no global load at all, so nothing in it waits (vmcnt is
+  // in-order) behind the NEXT panel's token rows, which are on their way from memory while it runs
+  for (int i = t; i < FF_C; i += FF_WAVES * 64) ((float*)(smem + FF_B2_OFF))[i] = p.b2[i];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned long long sp0 = (unsigned long long)(uintptr_t)p.wstream;
   const unsigned sp0lo = __builtin_amdgcn_readfirstlane((unsigned)sp0), sp0hi = __builtin_amdgcn_readfirstlane((unsigned)(sp0 >> 32));
@@ -163,6 +174,16 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
     // ---- the NEXT panel's token rows start their way from memory now: they land under this panel's epilogue
     const int nextp = panel + (int)gridDim.x;
     half8_t nraw[20], npv[20];
+    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+    uint4_t r2raw[20];
+    if (R2) {       // the second residual of THIS panel first: loads return in order
+      int lane3;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane3));
+      const long long tk = (long long)panel * (FF_WAVES * 32) + w * 32 + (lane3 & 31);
+      const half_t* rp = p.res2 + (tk < p.T ? tk : p.T - 1) * p.ldr2 + 8 * (lane3 >> 5);
+#pragma unroll
+      for (int ks = 0; ks < 20; ++ks) r2raw[ks] = *(const uint4_t*)(rp + 16 * ks);
+    }
     if (nextp < p.npanels) load_rows(nextp, nraw, npv, false);
 
     // ---- epilogue: lane (token, h) owns accumulator r of output tile i = channel 32 i + (r & 3) + 8 (r >> 2) + 4 h.  The
@@ -177,8 +198,7 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
     const long long tok2 = (long long)panel * (FF_WAVES * 32) + w * 32 + l2;
     const long long tok2c = tok2 < p.T ? tok2 : p.T - 1;
     const bool live = tok2 < p.T;
-    const half_t* r2p = R2 ? p.res2 + tok2c * p.ldr2 + 8 * h2 : nullptr;
-    const float* b2p = p.b2 + 4 * h2;
+    const float* b2p = (const float*)(smem + FF_B2_OFF) + 4 * h2;
     half_t* op = p.out + tok2c * p.ldo + 8 * h2;
     const float sa = p.s_acc, r2 = p.r2;
 #ifdef FF_X_NOEPI       /* timing knob: no epilogue (one accumulator read keeps the statement alive) */
@@ -196,15 +216,14 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
       z[1] = __builtin_bit_cast(unsigned, ff_agpr_read<FF_ZF + 4 * ks + 1>());
       z[2] = __builtin_bit_cast(unsigned, ff_agpr_read<FF_ZF + 4 * ks + 2>());
       z[3] = __builtin_bit_cast(unsigned, ff_agpr_read<FF_ZF + 4 * ks + 3>());
-      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(z[0]), "+v"(z[2]));
-      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(z[1]), "+v"(z[3]));
+      ff_swap32(z[0], z[2]);
+      ff_swap32(z[1], z[3]);
       unsigned rr[4];
       if (R2) {        // the second residual: 16 bytes of the lane's STORE group, exchanged back into the accumulator layout
-        typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
-        const uint4_t rv = *(const uint4_t*)(r2p + 16 * ks);
+        const uint4_t rv = r2raw[ks];
         rr[0] = rv[0]; rr[1] = rv[1]; rr[2] = rv[2]; rr[3] = rv[3];
-        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(rr[0]), "+v"(rr[2]));
-        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(rr[1]), "+v"(rr[3]));
+        ff_swap32(rr[0], rr[2]);
+        ff_swap32(rr[1], rr[3]);
       }
       unsigned o[4];
       ff_static_for([&](auto jc) {
@@ -230,9 +249,8 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
       }, FfIC<0>{}, FfIC<1>{});
       // lanes 0..31 (channels 0..3 | 8..11 of the k-step) give away 8..11 and take the partner's 4..7; lanes 32..63 hold
       // 8..15 afterwards: both halves have their eight channels in order
-      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(o[0]), "+v"(o[2]));
-      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(o[1]), "+v"(o[3]));
-      typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+      ff_swap32(o[0], o[2]);
+      ff_swap32(o[1], o[3]);
       if (live) *(uint4_t*)(op + 16 * ks) = (uint4_t){o[0], o[1], o[2], o[3]};
     });
 

@@ -32,15 +32,17 @@ NL = r"\n\t"
 VB = 24
 HT = {("h", 0): VB, ("g", 0): VB + 16, ("h", 1): VB + 32, ("g", 1): VB + 48}
 G_ = {0: VB + 64, 1: VB + 72}
+NRING = 8                 # fragment ring slots (4 registers each), read NRING MFMAs ahead
 RING = VB + 80
-TMP = VB + 96              # 8 temporaries: two elements in flight x (t, e/q, z, m)
-VEND = VB + 104
+TMP = RING + 4 * NRING      # 8 temporaries: two elements in flight x (t, e/q, z, m)
+VEND = TMP + 8
 YACC, ZF, ONESB, AEND = 0, 160, 240, 244
 NKS = 20
 W1_FR, W2_FR = NKS + 1, 20
 W1_BYTES, W2_BYTES = W1_FR * 1024, W2_FR * 1024
 SLOT = 24576
 NSLOT = 6
+WAITN = 4                 # fragment MFMAs per counted lgkmcnt wait
 NUNIT = 20
 # named SGPRs (clobbered inside the statement only; everything that lives across statements is an operand)
 SC = {"c1": 60, "c2": 61, "a1": 62, "a2": 63, "a3": 64, "a4": 65, "a5": 66}      # GELU constants
@@ -176,16 +178,16 @@ class Gen:
         nfr = W1_FR if ctype in ("h", "g") else W2_FR
         tags = [(cname, i) for i in range(nfr)]
         for i in range(nfr):
-            if i == nfr - 4 and nxt is not None:
+            if i == nfr - NRING and nxt is not None:
                 # ---- the next chunk becomes visible: own pieces landed, everybody's published
                 assert not self.pending_dma, "the previous chunk's DMA is still being issued"
                 self.e("s_waitcnt vmcnt(%d)" % wait_n, "waitvm")
                 self.e("s_barrier", "barrier")
                 if dma is not None:
                     self.pending_dma = self.dma_items(*dma)
-            if i % 2 == 0:
-                self.e("WAITFRAG", "waitfrag", frag=tags[min(i + 1, nfr - 1)])
-            rs = self.ringpos % 4         # ring slots rotate over ALL fragment MFMAs (a W1 chunk has 21)
+            if i % WAITN == 0:            # one counted wait per WAITN fragment MFMAs
+                self.e("WAITFRAG", "waitfrag", frag=tags[min(i + WAITN - 1, nfr - 1)])
+            rs = self.ringpos % NRING     # ring slots rotate over ALL fragment MFMAs (a W1 chunk has 21)
             self.ringpos += 1
             reg = RING + 4 * rs
             if ctype in ("h", "g"):
@@ -205,8 +207,8 @@ class Gen:
                 self.e("v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (ar(d, 16), vr(reg, 4), vr(b, 4), c), "mfma",
                        rd=R(reg, 4) + R(b, 4) + ([] if c == "0" else R(d, 16, "a")), wr=R(d, 16, "a"), frag=tags[i],
                        acc=c != "0")
-            # fragment four ahead (this chunk's, or the next chunk's first four)
-            j = i + 4
+            # fragment NRING ahead (this chunk's, or the next chunk's first ones)
+            j = i + NRING
             if j < nfr:
                 self.read_frag(slot, j, rs, tags[j])
             elif nxt is not None:
@@ -262,7 +264,7 @@ class Gen:
         self.pending_dma = self.dma_items(3, "w1", W1_BYTES)
         self.emit_dma(len(self.pending_dma))
         self.ringpos = 0
-        for j in range(4):
+        for j in range(NRING):
             self.read_frag(0, j, j, ("c0", j))
 
         def unit(u_kind):
@@ -307,8 +309,11 @@ class Gen:
                         self.nop(2)
 
         unit("first")
-        e("s_mov_b32 s%d, %d" % (SUNIT, NUNIT - 2), "salu")
+        # (a unit has 124 fragment MFMAs: with an eight-slot ring the slot rotation repeats every TWO units)
+        assert (NUNIT - 2) % 2 == 0
+        e("s_mov_b32 s%d, %d" % (SUNIT, (NUNIT - 2) // 2), "salu")
         self.label("LOOP")
+        unit("loop")
         unit("loop")
         e("s_sub_u32 s%d, s%d, 1" % (SUNIT, SUNIT), "salu")
         e("s_cmp_lg_u32 s%d, 0" % SUNIT, "salu")
@@ -407,7 +412,7 @@ class Gen:
                 n = i.meta["n"]
                 pending = pending[len(pending) - n:] if n else []
             elif i.kind == "mfma":
-                regs = [r for r in i.rd if r[0] == "v" and RING <= r[1] < RING + 16]
+                regs = [r for r in i.rd if r[0] == "v" and RING <= r[1] < RING + 4 * NRING]
                 assert len(regs) == 4
                 want = i.meta["frag"]
                 for r in regs:
