@@ -35,7 +35,8 @@ G_ = {0: VB + 64, 1: VB + 72}
 NRING = 8                 # fragment ring slots (4 registers each), read NRING MFMAs ahead
 RING = VB + 80
 TMP = RING + 4 * NRING      # 8 temporaries: two elements in flight x (t, e/q, z, m)
-VEND = TMP + 8
+CA4 = TMP + 8               # the polynomial's constant term in a register (v_fma takes one scalar operand)
+VEND = TMP + 10
 YACC, ZF, ONESB, AEND = 0, 160, 240, 244
 NKS = 20
 W1_FR, W2_FR = NKS + 1, 20
@@ -109,8 +110,7 @@ class Gen:
                 ("v_mul_f32_e32 %s, %s, %s" % (v(Z), s("c2"), v(Z)), "valu", [("v", Z)], [("v", Z)]),
                 ("v_max_f32_e32 %s, 0, %s" % (v(M), v(x)), "valu", [("v", x)], [("v", M)]),
                 ("v_exp_f32_e64 %s, -%s" % (v(E), v(Z)), "trans", [("v", Z)], [("v", E)]),
-                ("v_mov_b32_e32 %s, %s" % (v(Z), s("a4")), "valu", [], [("v", Z)]),
-                ("v_fma_f32 %s, %s, %s, %s" % (v(Z), v(T), s("a5"), v(Z)), "valu", [("v", T), ("v", Z)], [("v", Z)]),
+                ("v_fma_f32 %s, %s, %s, %s" % (v(Z), v(T), s("a5"), v(CA4)), "valu", [("v", T), ("v", CA4)], [("v", Z)]),
                 ("v_fma_f32 %s, %s, %s, %s" % (v(Z), v(Z), v(T), s("a3")), "valu", [("v", T), ("v", Z)], [("v", Z)]),
                 ("v_fma_f32 %s, %s, %s, %s" % (v(Z), v(Z), v(T), s("a2")), "valu", [("v", T), ("v", Z)], [("v", Z)]),
                 ("v_fma_f32 %s, %s, %s, %s" % (v(Z), v(Z), v(T), s("a1")), "valu", [("v", T), ("v", Z)], [("v", Z)]),
@@ -140,31 +140,37 @@ class Gen:
         `slot` and move the pointer behind it (adv = bytes, or "wrap": back to the stream start).  Pieces w + 4j (j < 5)
         through the five offset registers; the 21st KiB of a W1 chunk (the bias fragment) by every wave (same bytes, same
         place).  An s_nop separates every M0 write from its LDS-DMA."""
-        it = []
+        it = []          # pairs (M0 write, LDS-DMA): emitted around an MFMA, which is the wait state between the two
         for j in range(5):
-            it.append(("s_add_u32 m0, %%[ldsw], %d" % (slot * SLOT + j * 4096), "salu"))
-            it.append(("s_nop 0", "nop"))
-            it.append(("global_load_lds_dwordx4 %%[vo%d], s[%d:%d]" % (j, SP, SP + 1), "vmem"))
+            it.append(("s_add_u32 m0, %%[ldsw], %d" % (slot * SLOT + j * 4096),
+                       "global_load_lds_dwordx4 %%[vo%d], s[%d:%d]" % (j, SP, SP + 1)))
         if kind == "w1":
-            it.append(("s_add_u32 m0, %%[lds0], %d" % (slot * SLOT + 20480), "salu"))
-            it.append(("s_nop 0", "nop"))
-            it.append(("global_load_lds_dwordx4 %%[vob], s[%d:%d]" % (SP, SP + 1), "vmem"))
+            it.append(("s_add_u32 m0, %%[lds0], %d" % (slot * SLOT + 20480),
+                       "global_load_lds_dwordx4 %%[vob], s[%d:%d]" % (SP, SP + 1)))
         if adv == "wrap":
-            it.append(("s_mov_b32 s%d, %%[sp0lo]" % SP, "salu"))
-            it.append(("s_mov_b32 s%d, %%[sp0hi]" % (SP + 1), "salu"))
+            it.append(("s_mov_b32 s%d, %%[sp0lo]" % SP, "s_mov_b32 s%d, %%[sp0hi]" % (SP + 1)))
         else:
-            it.append(("s_add_u32 s%d, s%d, %d" % (SP, SP, adv), "salu"))
-            it.append(("s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1), "salu"))
+            it.append(("s_add_u32 s%d, s%d, %d" % (SP, SP, adv), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1)))
         return it
 
-    def emit_dma(self, n):
-        for _ in range(n):
-            if self.pending_dma:
-                t, k = self.pending_dma.pop(0)
-                if k == "nop":
-                    self.nop(0)
-                else:
-                    self.e(t, k)
+    def dma_first(self):
+        """first half of the next pending DMA pair (an M0 write or the pointer's low word): goes in FRONT of an MFMA"""
+        if self.pending_dma:
+            self.e(self.pending_dma[0][0], "salu")
+            self.dma_half = True
+
+    def dma_second(self):
+        """second half (the LDS-DMA itself / the pointer's high word): behind that MFMA"""
+        if getattr(self, "dma_half", False):
+            t = self.pending_dma.pop(0)[1]
+            self.e(t, "vmem" if t.startswith("global_load") else "salu")
+            self.dma_half = False
+
+    def emit_dma_all(self):
+        while self.pending_dma:
+            self.dma_first()
+            self.nop(0)
+            self.dma_second()
 
     # ---- one chunk ----------------------------------------------------------------------------------------------------------
     def chunk(self, cname, ctype, f, slot, fillers, nxt, dma, wait_n, first_y=False, fill_from=0, flush=False):
@@ -185,6 +191,7 @@ class Gen:
                 self.e("s_barrier", "barrier")
                 if dma is not None:
                     self.pending_dma = self.dma_items(*dma)
+            self.dma_first()
             if i % WAITN == 0:            # one counted wait per WAITN fragment MFMAs
                 self.e("WAITFRAG", "waitfrag", frag=tags[min(i + WAITN - 1, nfr - 1)])
             rs = self.ringpos % NRING     # ring slots rotate over ALL fragment MFMAs (a W1 chunk has 21)
@@ -213,7 +220,7 @@ class Gen:
                 self.read_frag(slot, j, rs, tags[j])
             elif nxt is not None:
                 self.read_frag(nxt[0], j - nfr, rs, (nxt[1], j - nfr))
-            self.emit_dma(3)
+            self.dma_second()
             # VALU fillers: an equal share of what is left for their window
             if fillers is not None and i >= fill_from:
                 q, left = fillers["q"], fillers["gaps"]
@@ -237,6 +244,7 @@ class Gen:
             e("s_mov_b32 s%d, 0x%08x" % (SC[k], fbits(val)), "salu")
         e("s_mov_b32 s%d, %%[splo]" % SP, "salu")
         e("s_mov_b32 s%d, %%[sphi]" % (SP + 1), "salu")
+        e("v_mov_b32_e32 %s, s%d" % (v(CA4), SC["a4"]), "valu", wr=[("v", CA4)])
         # ones operand of the bias k-step: k-slots 0, 1 of the h = 0 lanes
         e("v_and_b32_e32 %s, 0x3c003c00, %%[hmask]" % v(TMP), "valu", wr=[("v", TMP)])
         e("v_accvgpr_write_b32 a%d, %s" % (ONESB, v(TMP)), "valu", rd=[("v", TMP)], wr=[("a", ONESB)])
@@ -262,7 +270,7 @@ class Gen:
 
         # ---- statement start: the DMA of chunk 3 (unit 0's c4) and the first fragments of chunk 0
         self.pending_dma = self.dma_items(3, "w1", W1_BYTES)
-        self.emit_dma(len(self.pending_dma))
+        self.emit_dma_all()
         self.ringpos = 0
         for j in range(NRING):
             self.read_frag(0, j, j, ("c0", j))
@@ -319,7 +327,7 @@ class Gen:
         e("s_cmp_lg_u32 s%d, 0" % SUNIT, "salu")
         e("s_cbranch_scc1 LOOP_%=", "branch", target="LOOP")
         unit("last")
-        self.emit_dma(len(self.pending_dma))
+        self.emit_dma_all()
         self.nop(15)
         self.nop(15)
         e("s_mov_b32 %%[splo], s%d" % SP, "salu")
