@@ -102,7 +102,8 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
 #pragma unroll
     for (int ks = 0; ks < 20; ++ks) {
       if (!bias_only) {
-#ifdef FF_X_NOPRO      /* timing knob (tools/micro/ff_knobs.sh): no token loads */
+#ifdef FF_X_NOPRO      /* timing knob (tools/micro/ff_knobs.sh): no token loads.  CAUTION: constant rows make constant MFMA
+                          operands, and the chip clocks higher on those - this knob overstates what the loads cost (use NOLN) */
         raw[ks] = (half8_t){1, 2, 3, 4, 5, 6, 7, (half_t)ks};
 #else
         raw[ks] = *(const half8_t*)(xp + 16 * ks);
@@ -256,6 +257,9 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
 
     if (nextp < p.npanels) {
       if (PE) load_rows(nextp, nraw, npv, true);        // (the small row-bias table: L2-resident, loaded late to save registers)
+#ifdef FF_X_NOLN        /* timing knob: the next panel keeps this one's operands */
+      if (p.eps == 12345.f)
+#endif
       layernorm_rows(nraw, npv, ln_mean, ln_sigma);
     }
   }
