@@ -113,7 +113,10 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
     }
   };
   // LayerNorm of x' = x (+ row bias) in registers -> fp16 MFMA operands a[160:239]; returns mean and sigma of the row
+  // (No implicit contraction here: the lambda is instantiated twice - first panel, later panels - and a token row must give
+  // the same bits in both, or the two CFG halves of a batch, identical rows in different panels, drift apart by an fp16 ulp.)
   auto layernorm_rows = [&](half8_t (&raw)[20], half8_t (&pv)[20], float& ln_mean, float& ln_sigma) {
+#pragma clang fp contract(off)
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 20; ++ks) {
@@ -122,13 +125,13 @@ __global__ __launch_bounds__(FF_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(25
         float f = (float)raw[ks][e];
         if (PE) f += (float)pv[ks][e];
         s += f;
-        q += f * f;
+        q = fmaf(f, f, q);
       }
     }
     s += __shfl_xor(s, 32, 64);
     q += __shfl_xor(q, 32, 64);
     const float mean = s * (1.0f / FF_C);
-    float var = q * (1.0f / FF_C) - mean * mean;
+    float var = fmaf(-mean, mean, q * (1.0f / FF_C));
     var = var < 0.f ? 0.f : var;
     const float rstd = __builtin_amdgcn_rsqf(var + p.eps);
     const float nm = -mean * rstd;

@@ -9,6 +9,7 @@ import os
 import socket
 
 import pytest
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -24,6 +25,13 @@ def _free_port():
     return p
 
 
+def _ship(res):
+    """tensors leave a worker as numpy arrays, pickled BY VALUE: a torch tensor in a multiprocessing queue travels as a file
+    descriptor the parent has to fetch from the worker's resource-sharer socket - gone if the worker has exited by then
+    (seen once on a GPU box: FileNotFoundError in rebuild_storage_fd)"""
+    return {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in res.items()}
+
+
 def _collect(procs, q, world, timeout=600):
     """one result per rank; a rank that dies (exception in the worker) fails the test at once instead of letting the
     parent sit in q.get until the timeout"""
@@ -32,7 +40,8 @@ def _collect(procs, q, world, timeout=600):
     results, t0 = [], time.time()
     while len(results) < world:
         try:
-            results.append(q.get(timeout=2))
+            got = q.get(timeout=2)
+            results.append({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in got.items()})
         except queue.Empty:
             dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
             assert not dead, f"worker process exited with {dead}"
@@ -91,7 +100,7 @@ def _worker(rank, world, port, frames, guidance_on, q):
             ref = pipe.denoise((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2,
                                1.0, gmax)
             res["ref"] = ref.float().cpu()
-        q.put(res)
+        q.put(_ship(res))
     finally:
         dist.destroy_process_group()
 
@@ -131,7 +140,7 @@ def _worker_cn(rank, world, port, frames, q):
             res["ref"] = pipe.denoise(*args, domain_features=dom.to(dev), flow_features=flow.to(dev),
                                       controlnet_condition=ctrl.to(dev), controlnet_cond_scale=0.8).float().cpu()
             res["plain"] = pipe.denoise(*args, domain_features=dom.to(dev), flow_features=flow.to(dev)).float().cpu()
-        q.put(res)
+        q.put(_ship(res))
     finally:
         dist.destroy_process_group()
 
@@ -182,7 +191,7 @@ def _worker_dit(rank, world, port, q):
         if rank == 0:
             res["ref"] = pc.denoise(m, pc.CogVideoXDDIMScheduler(), lat.to(dev), img.to(dev), pe.to(dev), dom.to(dev), flow.to(dev),
                                     3, 6.0, True).float().cpu()
-        q.put(res)
+        q.put(_ship(res))
     finally:
         dist.destroy_process_group()
 

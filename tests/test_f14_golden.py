@@ -83,7 +83,7 @@ def _worker(rank, world, port, gpath, wpath, q):
         lat = (g["latents0"] * float(pipe.scheduler.init_noise_sigma)).half().to(dev)
         out = runner.denoise(lat, g["image_latents"].half().to(dev), g["image_embeddings"].half().to(dev), ids.to(dev), 2, 1.0, 3.0)
         print(f"[rank {rank}] 2 Euler steps done after {time.time() - t0:.0f} s", flush=True)
-        q.put({"rank": rank, "out": out.float().cpu()})
+        q.put({"rank": rank, "out": out.float().cpu().numpy()})
     finally:
         dist.destroy_process_group()
 

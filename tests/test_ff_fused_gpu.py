@@ -108,3 +108,25 @@ def test_ff_fused_equals_the_three_launch_chain():
     ops.gemm(mid, pack_linear(w2).to(DEV), chain, M=T, N=320, K=1280, bias=b2.to(DEV), res1=x)
     assert (fused.float() - chain.float()).abs().max().item() < 1.5e-2
     assert ((fused.float() - chain.float()).norm() / chain.float().norm()).item() < 2e-3
+
+
+def test_ff_fused_same_row_same_bits_wherever_it_sits():
+    """A token row gives the same output bits in whichever panel, wave and workgroup turn it is processed (the first panel of
+    a workgroup is normalised by other code than the later ones): the two CFG halves of a batch - the same rows 1008 panels
+    apart at the 72x128 level - must agree bitwise for test_full_size_loop_properties' guidance identity to hold."""
+    from lkgd_amd import ops
+    w1, b1, w2, b2, gamma, beta = _weights(21)
+    g = torch.Generator().manual_seed(22)
+    Fr, HW = 14, 9216
+    Th = Fr * HW                                   # 1008 panels per half; a launch has 256 workgroups
+    x0 = (torch.randn(Th, 320, generator=g) * 1.5).half().to(DEV)
+    r0 = torch.randn(Th, 320, generator=g).half().to(DEV)
+    x, res2 = torch.cat([x0, x0]), torch.cat([r0, r0])
+    pe = (0.5 * torch.randn(Fr, 320, generator=g)).half().to(DEV)
+    ws = _pack(w1, b1, w2, gamma, beta)
+    out = torch.empty_like(x)
+    for what, kw in (("plain", {}), ("row bias", dict(rowbias=pe, rowmap=ops.rowmap_div_mod(HW, Fr))),
+                     ("blend", dict(s_acc=0.3, res2=res2, r2=0.7))):
+        out.fill_(float("nan"))
+        ops.ff_fused(x, ws, b2.to(DEV), out, **kw)
+        assert torch.equal(out[:Th], out[Th:]), what
