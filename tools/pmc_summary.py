@@ -39,13 +39,13 @@ def main(fetch_csv, write_csv, json_out=None):
         fetch_b = fsum * 1024 * 2
         write_b = wsum * 1024
         rows.append((ns, k, n, fetch_b / n / 1e6, write_b / n / 1e6, (fetch_b + write_b) / ns))
-    for ns, k, n, f, w, bw in sorted(rows, reverse=True)[:12]:
+    for ns, k, n, f, w, bw in sorted(rows, reverse=True)[:24]:
         print(f"{k[:44]:44s} {n:8d} {f:30.2f} {w:16.2f} {bw:22.1f}")
 
 
     if json_out:
         import json
-        fam = {k: v for k, v in fe.items() if "lkgd_gemm" in k}
+        fam = {k: v for k, v in fe.items() if "lkgd_gemm" in k or "ff_fused" in k}      # what ops.GEMM_EVENTS times
         launches = sum(v[0] for v in fam.values())
         total = sum(v[1] * 1024 * 2 for v in fam.values()) + sum(wr.get(k, [0, 0.0, 0.0])[1] * 1024 for k in fam)
         doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 0 "
