@@ -162,6 +162,21 @@ int lkgd_layernorm(const void* x, int32_t ldx, int64_t T, int32_t C, const float
                    int32_t rb_md, void* out, int32_t ldo, lkgd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * 5c. The attention half of a temporal transformer block in one launch, C = 320 / 5 heads of 64 / F <= 16 (the 72x128 level):
+ *        out = W_o . attention_over_frames( q, k, v ) + b_o + x + rowbias[idx(row)],   q | k | v = W_qkv . LN(x) + b_qkv
+ *    x / out: [B*F*HW, 320] token rows, row = (b*F + f)*HW + pixel; every pixel attends over its own F frames (softmax scale
+ *    1/8); LN without affine (folded into W_qkv / b_qkv when the stream is packed); rowbias (may be NULL): fp16 table, idx as
+ *    in (1): ((row / rb_d1) * rb_m1 + row % rb_d2 + rb_c0) % rb_md - the block's one-token cross-attention folded to a table.
+ *    wstream: the chunk stream lkgd_amd/packing.py::pack_tblock builds (W_qkv, b_qkv, W_o in the order the kernel's generated
+ *    statement consumes them, 849 920 bytes).  Neither q | k | v nor the attention output is ever written.
+ *    Replaces: TemporalBasicTransformerBlock `norm1 -> attn1 -> + hidden_states` (patch/patch.py:592-597 regroup, :610,
+ *    :660-661; [EXT] diffusers Attention / F.scaled_dot_product_attention) and the `attn2` residual add of a one-token context.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_tattn_block_c320(const void* x, int32_t ldx, const void* wstream, const float* bo, const void* rowbias, int32_t ldrb,
+                          int32_t rb_d1, int32_t rb_m1, int32_t rb_d2, int32_t rb_md, int32_t rb_c0, void* out, int32_t ldo,
+                          int32_t B, int32_t F, int32_t HW, float eps, lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * 3b. LayerNorm + GEGLU feed-forward + output projection + residual(s) in one launch, C = 320 / inner 1280 (the 72x128
  *    level).  x' = x + rowbias[idx(row)] (idx = (row / rb_d1) % rb_md; rowbias may be NULL);
  *        out = s_acc * ( W2 . ( hidden * gelu(gate) ) + b2 + x' ) + r2 * res2,   [hidden | gate] = W1 . LN(x') + b1

@@ -1,0 +1,285 @@
+// The attention half of a temporal transformer block at the 72x128 level (C = 320, 5 heads of 64, F <= 16 frames) in ONE
+// kernel (include/lkgd_hip.h section 5c; round 4):
+//     out = to_out(softmax_over_frames(q k^T / 8) v) + x,   q | k | v = Linear(LayerNorm(x))
+// i.e. TemporalBasicTransformerBlock's `norm1 -> attn1 -> + hidden_states` (patch/patch.py:610, :660-661) on the
+// [B*F*HW, C] token rows of the clip: the [B*F,S,C] -> [B*S,F,C] regroup (:592-597) is the row addressing of this kernel.
+// It replaces the fused temporal front of round 3 (attn_tfront.hip: LayerNorm + QKV + attention) AND the out-projection GEMM
+// with its residual: the 165-MB attention output never reaches memory, and the projections of head h+1 run on the matrix
+// pipe while head h's softmax runs on the vector pipe.
+//
+// A wave owns 32 token rows = two pixels x 16 frame slots (slots >= F: the last frame's row again, masked as keys, never
+// stored) as MFMA operands (LayerNorm-ed in registers, parked in a[160:239]); a workgroup = 4 waves = 8 pixels = one panel.
+// The weights stream L2 -> LDS once per panel as 40 chunks in the order the generated statement consumes them
+// (tools/gen_tblock_asm.py -> attn_tblock_loop.inc, packing.pack_tblock); Y^T (320 x 32 per wave) lives in a[0:159].
+// This file is the prologue (token rows, LayerNorm) and the epilogue (bias, residual, store) around that statement - the
+// same as ff_fused.hip's.
+#include "common.h"
+#include "attn_tblock_loop.inc"
+
+#define TB_WAVES 4
+#define TB_C 320
+#define TB_PIX 8                               // pixels per panel
+#define TB_BO_OFF (TB_NSLOT * TB_SLOT)         // the out-projection bias, 320 floats behind the ring
+#define TB_LDS (TB_BO_OFF + TB_C * 4)
+
+template <int REG>
+__device__ __forceinline__ float tb_agpr_read() {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v) : "i"(REG));
+  return v;
+}
+template <int REG>
+__device__ __forceinline__ void tb_agpr_write(unsigned v) {
+  asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(v), "i"(REG));
+}
+// lanes 32..63 of `a` <-> lanes 0..31 of `b` (through the builtin: the compiler's hazard recogniser has to see it)
+__device__ __forceinline__ void tb_swap32(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+template <int V> struct TbIC { static constexpr int value = V; };
+template <class F, int... Is> __device__ __forceinline__ void tb_static_for(F&& f, TbIC<Is>...) { (f(TbIC<Is>{}), ...); }
+template <class F> __device__ __forceinline__ void tb_for20(F&& f) {
+  tb_static_for(f, TbIC<0>{}, TbIC<1>{}, TbIC<2>{}, TbIC<3>{}, TbIC<4>{}, TbIC<5>{}, TbIC<6>{}, TbIC<7>{}, TbIC<8>{}, TbIC<9>{},
+                TbIC<10>{}, TbIC<11>{}, TbIC<12>{}, TbIC<13>{}, TbIC<14>{}, TbIC<15>{}, TbIC<16>{}, TbIC<17>{}, TbIC<18>{}, TbIC<19>{});
+}
+
+struct tb_params {
+  const half_t* x; int ldx;
+  const half_t* rowbias; int ldrb; unsigned rb_d1, rb_m1, rb_d2, rb_md, rb_c0;
+  const char* wstream;
+  const float* bo;
+  float eps;
+  half_t* out; int ldo;
+  int F, HW;
+  long long npix;          // B * HW
+  int npanels;
+};
+
+// RB: a row-indexed bias joins the residual (the one-token cross-attention of the block, folded into a table: idx as in
+// lkgd_gemm_f16's epilogue)
+template <bool RB>
+__global__ __launch_bounds__(TB_WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(256))) void tattn_block_kernel(tb_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  if ((int)blockIdx.x >= p.npanels) return;
+
+  // ---- chunks 0..2 of the stream (every panel's statement issues the chunks three ahead, across panel borders)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const char* src = p.wstream + c * TB_W1_BYTES + lane * 16;
+    char* dst = smem + c * TB_SLOT;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) glds16(src + (w + 4 * j) * 1024, dst + (w + 4 * j) * 1024);
+    glds16(src + 20480, dst + 20480);
+  }
+  for (int i = t; i < TB_C; i += TB_WAVES * 64) ((float*)(smem + TB_BO_OFF))[i] = p.bo[i];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned long long sp0 = (unsigned long long)(uintptr_t)p.wstream;
+  const unsigned sp0lo = __builtin_amdgcn_readfirstlane((unsigned)sp0), sp0hi = __builtin_amdgcn_readfirstlane((unsigned)(sp0 >> 32));
+  unsigned splo, sphi;
+  {
+    const unsigned long long sp = sp0 + 3ull * TB_W1_BYTES;
+    splo = __builtin_amdgcn_readfirstlane((unsigned)sp);
+    sphi = __builtin_amdgcn_readfirstlane((unsigned)(sp >> 32));
+  }
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)w * 1024u);
+  const unsigned lds0u = __builtin_amdgcn_readfirstlane(lds0);
+  const unsigned fa0 = lds0 + lane * 16, fa1 = fa0 + 2 * TB_SLOT, fa2 = fa0 + 4 * TB_SLOT;
+  const unsigned vo0 = (unsigned)(w * 1024 + lane * 16), vo1 = vo0 + 4096, vo2 = vo0 + 8192, vo3 = vo0 + 12288, vo4 = vo0 + 16384;
+  const unsigned vob = 20480u + lane * 16;
+  const unsigned hmask = h == 0 ? 0xffffffffu : 0u;
+  // the softmax's view of a lane (query column l31, half h): its pixel is (l31 >> 4); the other half of the query's keys sits
+  // in lane ^ 32; key slot 8 jj + 4 h + i of the pixel is a frame iff it is < F
+  const unsigned xora = (unsigned)((lane ^ 32) * 4);
+  const int flim = p.F - 4 * h;
+  const float negbig = -30000.f;
+  const unsigned pm0 = (l31 >> 4) == 0 ? 0u : __builtin_bit_cast(unsigned, negbig);
+  const unsigned pm1 = (l31 >> 4) == 1 ? 0u : __builtin_bit_cast(unsigned, negbig);
+
+  // token row of (panel, wave, lane): pixel 8 panel + 2 w + (l31 >> 4) of the clip batch, frame slot l31 & 15
+  // (32-bit arithmetic: the host checks B * F * HW < 2^31)
+  auto row_of = [&](int panel, int l, bool& live) -> unsigned {
+    unsigned gp = (unsigned)panel * TB_PIX + (unsigned)w * 2 + (unsigned)(l >> 4);
+    const unsigned f = l & 15;
+    live = gp < (unsigned)p.npix && f < (unsigned)p.F;
+    gp = gp < (unsigned)p.npix ? gp : (unsigned)p.npix - 1;
+    const unsigned b = gp / (unsigned)p.HW, pix = gp - b * (unsigned)p.HW;
+    return (b * (unsigned)p.F + (f < (unsigned)p.F ? f : (unsigned)p.F - 1)) * (unsigned)p.HW + pix;
+  };
+  // the wave's 32 token rows of a panel: this lane holds channels 16 ks + 8 h + 0..7 of its row (the operand layout)
+  // (lane coordinates are parameters: behind the statement they are re-derived, so that nothing but the statement's own
+  // operands stays live across it - it leaves the compiler 56 vector registers)
+  auto load_rows = [&](int panel, int l, int hh, half8_t (&raw)[20]) {
+    bool live;
+    const half_t* xp = p.x + (long long)row_of(panel, l, live) * p.ldx + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 20; ++ks) raw[ks] = *(const half8_t*)(xp + 16 * ks);
+  };
+  // LayerNorm in registers -> fp16 MFMA operands a[160:239]; returns mean and sigma of the row.  (No implicit contraction:
+  // the lambda is instantiated twice and a row must give the same bits in both - see ff_fused.hip.)
+  auto layernorm_rows = [&](half8_t (&raw)[20], float& ln_mean, float& ln_sigma) {
+#pragma clang fp contract(off)
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 20; ++ks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)raw[ks][e];
+        s += f;
+        q = fmaf(f, f, q);
+      }
+    }
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float mean = s * (1.0f / TB_C);
+    float var = fmaf(-mean, mean, q * (1.0f / TB_C));
+    var = var < 0.f ? 0.f : var;
+    const float rstd = __builtin_amdgcn_rsqf(var + p.eps);
+    const float nm = -mean * rstd;
+    ln_mean = mean;
+    ln_sigma = (var + p.eps) * rstd;
+    tb_for20([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      asm volatile("" : "+v"(raw[ks]));        // (the second pass converts the fp16 rows again: see ff_fused.hip)
+      half8_t z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (half_t)fmaf((float)raw[ks][e], rstd, nm);
+      typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+      const uint4_t u = __builtin_bit_cast(uint4_t, z);
+      tb_agpr_write<TB_ZF + 4 * ks + 0>(u[0]);
+      tb_agpr_write<TB_ZF + 4 * ks + 1>(u[1]);
+      tb_agpr_write<TB_ZF + 4 * ks + 2>(u[2]);
+      tb_agpr_write<TB_ZF + 4 * ks + 3>(u[3]);
+    });
+  };
+
+  float ln_mean, ln_sigma;        // the epilogue rebuilds the residual x = z * sigma + mean from the normalised fragments
+  {
+    half8_t raw[20];
+    load_rows(blockIdx.x, l31, h, raw);
+    layernorm_rows(raw, ln_mean, ln_sigma);
+  }
+#pragma unroll 1
+  for (int panel = blockIdx.x; panel < p.npanels; panel += gridDim.x) {
+    asm volatile(TB_PANEL_ASM
+                 : [splo] "+s"(splo), [sphi] "+s"(sphi)
+                 : [fa0] "v"(fa0), [fa1] "v"(fa1), [fa2] "v"(fa2), [vo0] "v"(vo0), [vo1] "v"(vo1), [vo2] "v"(vo2), [vo3] "v"(vo3),
+                   [vo4] "v"(vo4), [vob] "v"(vob), [hmask] "v"(hmask), [xora] "v"(xora), [flim] "v"(flim), [pm0] "v"(pm0),
+                   [pm1] "v"(pm1), [ldsw] "s"(ldsw), [lds0] "s"(lds0u), [sp0lo] "s"(sp0lo), [sp0hi] "s"(sp0hi)
+                 : TB_CLOBBERS);
+
+    int lane2;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane2));
+    const int h2 = lane2 >> 5;
+    bool live;
+    const unsigned row2 = row_of(panel, lane2 & 31, live);
+    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+    uint4_t rbraw[20];
+    if (RB) {       // THIS panel's bias rows first (loads return in order): 16 bytes of the lane's store group per k-step
+      const unsigned mu = row2;
+      const unsigned idx = ((mu / p.rb_d1) * p.rb_m1 + (mu % p.rb_d2) + p.rb_c0) % p.rb_md;
+      const half_t* rp = p.rowbias + (long long)idx * p.ldrb + 8 * h2;
+#pragma unroll
+      for (int ks = 0; ks < 20; ++ks) rbraw[ks] = *(const uint4_t*)(rp + 16 * ks);
+    }
+    // ---- the NEXT panel's token rows start their way from memory now: they land under this panel's epilogue
+    const int nextp = panel + (int)gridDim.x;
+    // (UNCONDITIONAL, a workgroup's last panel fetches its own rows again: a conditionally defined array becomes a phi with
+    // undef, which the compiler keeps "live" through the whole loop - eighty registers the statement's clobbers do not leave)
+    half8_t nraw[20];
+    load_rows(nextp < p.npanels ? nextp : panel, lane2 & 31, h2, nraw);
+
+    // ---- epilogue (ff_fused.hip's): lane (token, h) owns accumulator r of output tile i = channel 32 i + (r & 3) + 8 (r >> 2)
+    //      + 4 h; the residual x is rebuilt from the normalised fragments in a[160:239]; half-wave exchanges pair the 4-channel
+    //      groups into 16-byte stores
+    const float* bop = (const float*)(smem + TB_BO_OFF) + 4 * h2;
+    half_t* op = p.out + (long long)row2 * p.ldo + 8 * h2;
+#ifdef TB_X_NOEPI       /* timing knob: no epilogue (one accumulator read keeps the statement alive) */
+    if (live && tb_agpr_read<TB_YACC>() == 12345.678f) *op = (half_t)1.f;
+    if (false)
+#endif
+    tb_for20([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      constexpr int i = ks >> 1, g0 = 2 * (ks & 1);
+      asm volatile("" ::: "memory");       // (a scheduling fence per k-step: see ff_fused.hip)
+      unsigned z[4];
+      z[0] = __builtin_bit_cast(unsigned, tb_agpr_read<TB_ZF + 4 * ks + 0>());
+      z[1] = __builtin_bit_cast(unsigned, tb_agpr_read<TB_ZF + 4 * ks + 1>());
+      z[2] = __builtin_bit_cast(unsigned, tb_agpr_read<TB_ZF + 4 * ks + 2>());
+      z[3] = __builtin_bit_cast(unsigned, tb_agpr_read<TB_ZF + 4 * ks + 3>());
+      tb_swap32(z[0], z[2]);
+      tb_swap32(z[1], z[3]);
+      unsigned rr[4];
+      if (RB) {        // 16 bytes of the lane's STORE group, exchanged back into the accumulator layout
+        const uint4_t rv = rbraw[ks];
+        rr[0] = rv[0]; rr[1] = rv[1]; rr[2] = rv[2]; rr[3] = rv[3];
+        tb_swap32(rr[0], rr[2]);
+        tb_swap32(rr[1], rr[3]);
+      }
+      unsigned o[4];
+      tb_static_for([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int c0 = 32 * i + 8 * (g0 + j);
+        const float4_t bb = *(const float4_t*)(bop + c0);
+        float4_t y;
+        y[0] = tb_agpr_read<TB_YACC + 16 * i + 4 * (g0 + j) + 0>();
+        y[1] = tb_agpr_read<TB_YACC + 16 * i + 4 * (g0 + j) + 1>();
+        y[2] = tb_agpr_read<TB_YACC + 16 * i + 4 * (g0 + j) + 2>();
+        y[3] = tb_agpr_read<TB_YACC + 16 * i + 4 * (g0 + j) + 3>();
+        const half2_t z0 = __builtin_bit_cast(half2_t, z[2 * j]), z1 = __builtin_bit_cast(half2_t, z[2 * j + 1]);
+        const float4_t xs = {fmaf((float)z0[0], ln_sigma, ln_mean), fmaf((float)z0[1], ln_sigma, ln_mean),
+                             fmaf((float)z1[0], ln_sigma, ln_mean), fmaf((float)z1[1], ln_sigma, ln_mean)};
+        float4_t ov = y + bb + xs;
+        if (RB) {
+          const half2_t q0 = __builtin_bit_cast(half2_t, rr[2 * j]), q1 = __builtin_bit_cast(half2_t, rr[2 * j + 1]);
+          ov += (float4_t){(float)q0[0], (float)q0[1], (float)q1[0], (float)q1[1]};
+        }
+        const half2_t a = {(half_t)ov[0], (half_t)ov[1]}, bq = {(half_t)ov[2], (half_t)ov[3]};
+        o[2 * j] = __builtin_bit_cast(unsigned, a);
+        o[2 * j + 1] = __builtin_bit_cast(unsigned, bq);
+      }, TbIC<0>{}, TbIC<1>{});
+      tb_swap32(o[0], o[2]);
+      tb_swap32(o[1], o[3]);
+      if (live) *(uint4_t*)(op + 16 * ks) = (uint4_t){o[0], o[1], o[2], o[3]};
+    });
+
+    if (nextp < p.npanels) layernorm_rows(nraw, ln_mean, ln_sigma);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the chunks issued ahead for a panel that does not come
+}
+
+extern "C" int lkgd_tattn_block_c320(const void* x, int32_t ldx, const void* wstream, const float* bo, const void* rowbias,
+                                     int32_t ldrb, int32_t rb_d1, int32_t rb_m1, int32_t rb_d2, int32_t rb_md, int32_t rb_c0,
+                                     void* out, int32_t ldo, int32_t B, int32_t F, int32_t HW, float eps, lkgd_stream_t stream) {
+  if (!x || !wstream || !bo || !out) return LKGD_E_NULL;
+  if (B <= 0 || F <= 0 || F > 16 || HW <= 0 || (long long)B * F * HW > 0x7fffffffLL) return LKGD_E_SHAPE;
+  if (rowbias && (ldrb % 8 || ldrb < TB_C || rb_d1 <= 0 || rb_d2 <= 0 || rb_md <= 0 || rb_m1 < 0 || rb_c0 < 0 || !aligned16(rowbias)))
+    return LKGD_E_SHAPE;
+  if (ldx % 8 || ldo % 8 || ldx < TB_C || ldo < TB_C) return LKGD_E_ALIGN;
+  if (!aligned16(x) || !aligned16(wstream) || !aligned16(out) || !aligned16(bo)) return LKGD_E_ALIGN;
+  LKGD_DEVICE_ONCE_BEGIN
+    if (hipFuncSetAttribute((const void*)tattn_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tattn_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS) != hipSuccess)
+      return LKGD_E_LAUNCH;
+  LKGD_DEVICE_ONCE_END
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  tb_params p;
+  p.rowbias = (const half_t*)rowbias; p.ldrb = ldrb;
+  p.rb_d1 = rb_d1 > 0 ? rb_d1 : 1; p.rb_m1 = rb_m1; p.rb_d2 = rb_d2 > 0 ? rb_d2 : 1; p.rb_md = rb_md > 0 ? rb_md : 1; p.rb_c0 = rb_c0;
+  p.x = (const half_t*)x; p.ldx = ldx; p.wstream = (const char*)wstream; p.bo = bo; p.eps = eps;
+  p.out = (half_t*)out; p.ldo = ldo; p.F = F; p.HW = HW; p.npix = (long long)B * HW;
+  const long long npanels = (p.npix + TB_PIX - 1) / TB_PIX;
+  if (npanels > 0x7fffffffLL) return LKGD_E_SHAPE;
+  p.npanels = (int)npanels;
+  const int grid = npanels < cus ? (int)npanels : cus;
+  if (rowbias) hipLaunchKernelGGL(tattn_block_kernel<true>, dim3(grid), dim3(TB_WAVES * 64), TB_LDS, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(tattn_block_kernel<false>, dim3(grid), dim3(TB_WAVES * 64), TB_LDS, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}

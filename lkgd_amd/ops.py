@@ -335,6 +335,40 @@ def tattn_front(x: torch.Tensor, wpack: torch.Tensor, bqkv: Optional[torch.Tenso
     return out
 
 
+def tattn_block(x: torch.Tensor, wstream: torch.Tensor, bo: torch.Tensor, out: torch.Tensor, B: int, F: int, HW: int,
+                rowbias: Optional[torch.Tensor] = None, rowmap: Optional[RowMap] = None, eps: float = 1e-5) -> torch.Tensor:
+    """out = to_out(attn1(LayerNorm(x))) + b_o + x (+ rowbias[rowmap(row)]): LayerNorm, Q|K|V, the attention over the F frames
+    of every pixel, the out-projection and the residual in one launch (lkgd_tattn_block_c320); x / out: [B*F*HW, 320]"""
+    _req(x, torch.float16, "x"); _req(wstream, torch.float16, "wstream"); _req(out, torch.float16, "out")
+    _req(bo, torch.float32, "bo")
+    if x.shape[0] != B * F * HW or out.shape[0] != x.shape[0]:
+        raise _lib.LkgdHipError("tattn_block: x / out must hold B * F * HW rows")
+    d1, m1, d2, md = rowmap[:4] if rowmap is not None else (1, 0, 1, 1)
+    c0 = rowmap[4] if rowmap is not None and len(rowmap) > 4 else 0
+    if rowbias is not None:
+        _req(rowbias, torch.float16, "rowbias")
+    nflop = 2 * x.shape[0] * (960 * 320 + 320 * 320) + 4 * x.shape[0] * 16 * 320
+    ev = GEMM_EVENTS        # a GEMM-family launch for bench.py's roofline line (projections, out-projection, 16 x 16 attention)
+    if ev is not None:
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+    check(_L().lkgd_tattn_block_c320(x.data_ptr(), _ld(x), wstream.data_ptr(), bo.data_ptr(), _ptr(rowbias),
+                                     _ld(rowbias) if rowbias is not None else 0, d1, m1, d2, min(md, 0x7fffffff), c0,
+                                     out.data_ptr(), _ld(out), B, F, HW, eps, _stream()), "lkgd_tattn_block_c320")
+    if ev is not None:
+        e_ev.record()
+        ev.append((s_ev, e_ev, float(nflop)))
+    return out
+
+
+def tattn_block_ok(C_: int, heads: int, F: int, HW: int) -> bool:
+    return TBLOCK and C_ == 320 and heads == 5 and 1 <= F <= 16
+
+
+#: A/B switch of the one-launch temporal attention (False = fused front + out-projection GEMM)
+TBLOCK = os.environ.get("LKGD_NO_TBLOCK", "0") != "1"
+
+
 def tattn_front_ok(C_: int, heads: int, F: int, HW: int) -> bool:
     return TFRONT and C_ == 320 and heads * 64 == C_ and 1 <= F <= 16 and HW % 16 == 0
 

@@ -46,6 +46,48 @@ def pack_tfront(wqkv: torch.Tensor, heads: int) -> torch.Tensor:
     return t.permute(1, 0, 2, 4, 5, 3, 6).contiguous().reshape(-1)
 
 
+def pack_tblock(wqkv: torch.Tensor, bqkv, wo: torch.Tensor, heads: int = 5) -> torch.Tensor:
+    """Chunk stream of lkgd_tattn_block_c320 (lkgd_amd/csrc/attn_tblock.hip, tools/gen_tblock_asm.py): the fused projection
+    wqkv [960, 320] (rows q | k | v, head-major, LayerNorm affine folded in) with bias bqkv [960] (or None), and the
+    out-projection wo [320, 320].  Returns fp16 [n] = 40 chunks in the order of tools/gen_tblock_asm.py::stream(): per head h
+        q0 q1 (h) | o0 o1 (h - 1; heads 1..3 only) | k0 k1 v0 v1 (h);  the stream ends with o0 o1 of heads 3 and 4.
+    q / k / v chunk (tile f = 32 of the head's 64 channels) = 21 MFMA fragments of 64 lanes x 8 halfs (lane = 32 hh + row):
+    fragment 0 carries the bias as (b_hi, b_lo) in k-slots 0, 1 of the hh = 0 lanes, fragments 1..20 W[base + row][16 ks + 8 hh
+    + e] - q and k use them as the A operand (rows = head channels), v as the B operand (columns = head channels): same bytes.
+    o chunk (tile f of head h) = 20 fragments (k-step ss, output tile ti): Wo[32 ti + row][64 h + 32 f + 16 ss + (e & 3) +
+    8 (e >> 2) + 4 hh] - the k-slot order in which the attention's accumulators hold the head channels."""
+    assert heads == 5 and wqkv.shape == (960, 320) and wo.shape == (320, 320)
+    dev = wqkv.device
+    w = wqkv.to(torch.float16).reshape(3, heads, 2, 32, 20, 2, 8)           # [which, h, f, row, ks, hh, e]
+    b = (bqkv if bqkv is not None else torch.zeros(960, device=dev)).to(torch.float32).reshape(3, heads, 2, 32)
+    b_hi = b.to(torch.float16)
+    b_lo = (b - b_hi.to(torch.float32)).to(torch.float16)
+    h_, e_ = torch.arange(2, device=dev)[:, None], torch.arange(8, device=dev)[None, :]
+    kidx = (e_ & 3) + 8 * (e_ >> 2) + 4 * h_                                 # [hh, e] -> position inside a 16-channel k-step
+    woh = wo.to(torch.float16).reshape(10, 32, heads, 2, 2, 16)              # [ti, row, h, f, ss, k16]
+
+    def proj_chunk(t, h, f):
+        bias = torch.zeros(2, 32, 8, dtype=torch.float16, device=dev)
+        bias[0, :, 0], bias[0, :, 1] = b_hi[t, h, f], b_lo[t, h, f]
+        body = w[t, h, f].permute(1, 2, 0, 3)                                # [ks, hh, row, e]
+        return torch.cat([bias.reshape(1, -1), body.reshape(20, -1)]).reshape(-1)
+
+    def out_chunk(h, f):
+        blk = woh[:, :, h, f][..., kidx]                                     # [ti, row, ss, hh, e]
+        return blk.permute(2, 0, 3, 1, 4).reshape(-1)                        # [ss, ti, hh, row, e]
+
+    chunks = []
+    for h in range(heads):
+        chunks += [proj_chunk(0, h, 0), proj_chunk(0, h, 1)]
+        if 0 < h < heads - 1:
+            chunks += [out_chunk(h - 1, 0), out_chunk(h - 1, 1)]
+        chunks += [proj_chunk(t, h, f) for t in (1, 2) for f in (0, 1)]
+    chunks += [out_chunk(h, f) for h in (heads - 2, heads - 1) for f in (0, 1)]
+    out = torch.cat(chunks).contiguous()
+    assert out.numel() * 2 == 30 * 21504 + 10 * 20480
+    return out
+
+
 def geglu_perm(inner: int, half: int = 32, device=None) -> torch.Tensor:
     """row permutation of the GEGLU projection [2*inner, K]: every 2*half packed rows = `half` hidden rows followed by
     their `half` gate rows (inner + ..), so that the output columns one wave owns hold both factors of its GEGLU

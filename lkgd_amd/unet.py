@@ -558,7 +558,11 @@ class TemporalBasicTransformerBlock(nn.Module):
         resharded = (ctx.frames_sharded and ctx.lora is None and not _dist.TEMPORAL_GATHER and
                      ctx.HW >= ctx.shard.plan.frame_shards)
         ln1 = None if (fused or resharded) else ops.layernorm(m1, None, None, 1e-5)
-        if fused:
+        # ... and the out-projection, its residual and the folded cross-attention table in the same launch (attn_tblock.hip)
+        one_launch = fused and ops.tattn_block_ok(Cc, self.attn1.heads, ctx.F, ctx.HW)
+        if one_launch:
+            pass
+        elif fused:
             if getattr(pk.a1, "wfront", None) is None:
                 from .packing import pack_tfront
                 pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
@@ -617,7 +621,12 @@ class TemporalBasicTransformerBlock(nn.Module):
         else:
             raise ValueError(order)
         m2 = ctx.new(T, Cc)
-        if va is None:
+        if one_launch:
+            if getattr(pk.a1, "wblock", None) is None:
+                from .packing import pack_tblock
+                pk.a1.wblock = pack_tblock(pk.a1.wqkv, pk.a1.bqkv, pk.a1.wo, self.attn1.heads)
+            ops.tattn_block(m1, pk.a1.wblock, pk.a1.bo, m2, ctx.B, ctx.F, ctx.HW, rowbias=xtab, rowmap=xmap)
+        elif va is None:
             ops.gemm(att, pk.a1.wo, m2, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=m1, rowbias=xtab, rowmap=xmap)
         else:
             b_off = ctx.b0 if order == "batch_major" else 0
