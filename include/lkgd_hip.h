@@ -247,6 +247,14 @@ int lkgd_prepare_unet_input(const void* latents, int32_t latents_is_f32, const v
 int lkgd_cfg_euler_step(const void* noise_tokens, void* latents, int32_t latents_is_f32, const float* guidance,
                         int32_t B, int32_t F, int32_t H, int32_t W, int32_t cfg, float sigma, float sigma_next,
                         int32_t prediction_type /*0 eps, 1 v*/, lkgd_stream_t stream);
+/* Frame-sharded ranks: rows of this rank's [fl, HW, C] fp16 slice regrouped by destination pixel shard (pack != 0: the send
+ * buffer of the all-to-all that re-shards the temporal attention by pixels - row (f, p) goes to fl*p0[r] + f*px[r] + (p - p0[r]),
+ * r = the shard owning pixel p, px[0..k-1] = pixels per shard, k <= 16, sum = HW) or back (pack == 0: dst is the [fl, HW, C]
+ * slice).  One launch instead of k strided copies on either side of every exchange.  px is a HOST array (read before return).
+ * Replaces: the chunk / cat re-layout around torch.distributed.all_to_all_single in sequence-parallel attention
+ * (CogVideo-main/tools/parallel_inference/parallel_inference_xdit.py:47-52 is the reference's only statement of it). */
+int lkgd_shard_rows(const void* src, void* dst, int32_t fl, int32_t HW, int32_t C, int32_t k, const int32_t* px, int32_t pack,
+                    lkgd_stream_t stream);
 int lkgd_tokens_to_nchw(const void* tokens, int32_t ld, int64_t N, int32_t C, int32_t HW, void* out,
                         lkgd_stream_t stream);
 int lkgd_nchw_to_tokens(const void* nchw, int64_t N, int32_t C, int32_t HW, void* tokens, int32_t ld,

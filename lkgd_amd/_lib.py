@@ -77,6 +77,7 @@ SYMBOLS = {
     "lkgd_tattn_front": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
     "lkgd_prepare_unet_input": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "lkgd_cfg_euler_step": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
+    "lkgd_shard_rows": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "lkgd_tokens_to_nchw": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "lkgd_nchw_to_tokens": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "lkgd_timestep_embedding": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp]),

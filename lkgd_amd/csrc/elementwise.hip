@@ -200,6 +200,49 @@ extern "C" int lkgd_cfg_euler_step(const void* noise_tokens, void* latents, int3
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 
+// ---- rows of a frame shard regrouped by destination pixel shard (and back): the pack / unpack around the all-to-all that
+// re-shards the temporal attention by pixels (lkgd_amd/dist.py::frames_to_pixels / pixels_to_frames).  Row (f, p) of the
+// [fl, HW, C] slice sits in the send buffer at  fl * p0[r] + f * px[r] + (p - p0[r])  with r = the shard that owns pixel p.
+typedef unsigned sr_vec_t __attribute__((ext_vector_type(4)));
+struct shard_tab { int k; int px[16]; int p0[16]; };
+template <bool PACK>
+__global__ __launch_bounds__(256) void shard_rows_kernel(const sr_vec_t* __restrict__ src, sr_vec_t* __restrict__ dst, int fl, int HW,
+                                                         int c8, shard_tab tab) {
+  const long long n = (long long)fl * HW * c8;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long row = i / c8;
+    const int v = (int)(i - row * c8);
+    const int f = (int)(row / HW), p = (int)(row - (long long)f * HW);
+    int r = 0;
+    while (r + 1 < tab.k && p >= tab.p0[r + 1]) ++r;
+    const long long prow = (long long)fl * tab.p0[r] + (long long)f * tab.px[r] + (p - tab.p0[r]);
+    if (PACK) dst[prow * c8 + v] = src[i];
+    else dst[i] = src[prow * c8 + v];
+  }
+}
+
+extern "C" int lkgd_shard_rows(const void* src, void* dst, int32_t fl, int32_t HW, int32_t C, int32_t k, const int32_t* px,
+                               int32_t pack, lkgd_stream_t stream) {
+  if (!src || !dst || !px) return LKGD_E_NULL;
+  if (fl <= 0 || HW <= 0 || C <= 0 || C % 8 || k <= 0 || k > 16) return LKGD_E_SHAPE;
+  if (!aligned16(src) || !aligned16(dst)) return LKGD_E_ALIGN;
+  shard_tab tab;
+  tab.k = k;
+  int o = 0;
+  for (int r = 0; r < k; ++r) {
+    if (px[r] <= 0) return LKGD_E_SHAPE;
+    tab.px[r] = px[r];
+    tab.p0[r] = o;
+    o += px[r];
+  }
+  if (o != HW) return LKGD_E_SHAPE;
+  const long long n = (long long)fl * HW * (C / 8);
+  const dim3 gr(grid_for(n, 256)), bl(256);
+  if (pack) hipLaunchKernelGGL(shard_rows_kernel<true>, gr, bl, 0, (hipStream_t)stream, (const sr_vec_t*)src, (sr_vec_t*)dst, fl, HW, C / 8, tab);
+  else hipLaunchKernelGGL(shard_rows_kernel<false>, gr, bl, 0, (hipStream_t)stream, (const sr_vec_t*)src, (sr_vec_t*)dst, fl, HW, C / 8, tab);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
 extern "C" int lkgd_tokens_to_nchw(const void* tokens, int32_t ld, int64_t N, int32_t C, int32_t HW, void* out,
                                    lkgd_stream_t stream) {
   if (!tokens || !out) return LKGD_E_NULL;

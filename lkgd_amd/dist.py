@@ -28,6 +28,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
+import os
 import torch
 import torch.distributed as dist
 
@@ -158,6 +159,12 @@ def pixel_splits(HW: int, shards: int) -> Tuple[int, ...]:
     return tuple((q + 1 if i < r else q) * unit for i in range(shards))
 
 
+def _hip_rows(t: torch.Tensor, C: int) -> bool:
+    """the pack / unpack around a re-sharding exchange runs as one HIP launch (fp16 rows of whole 16-byte vectors on the GPU);
+    CPU tensors (the gloo tests) and other dtypes keep the strided copies"""
+    return t.is_cuda and t.dtype == torch.float16 and C % 8 == 0 and os.environ.get("LKGD_NO_SHARD_ROWS", "0") != "1"
+
+
 def all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_rows: List[int], in_rows: List[int], group=None) -> None:
     """dist.all_to_all_single over dim 0 with per-peer row counts; gloo with device tensors is staged through host memory"""
     if _backend(group) == "nccl" or not inp.is_cuda:
@@ -189,9 +196,15 @@ def frames_to_pixels(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.
         pieces.append((send[o:o + in_rows[r]].view(fl, px[r], C), local[:, p0[r]:p0[r] + px[r], :]))
         o += in_rows[r]
 
+    one_launch = _hip_rows(local, C)
+
     def step():
-        for dst, src in pieces:
-            dst.copy_(src)
+        if one_launch:            # the k strided copies as one kernel (lkgd_shard_rows)
+            from . import ops
+            ops.shard_rows(local, send, fl, HW, C, px, True)
+        else:
+            for dst, src in pieces:
+                dst.copy_(src)
         all_to_all_rows(recv, send, out_rows, in_rows, group)
     _step(step)
     return recv.view(plan.num_frames, px[si], C)
@@ -218,10 +231,16 @@ def pixels_to_frames(x: torch.Tensor, plan: ShardPlan, HW: int, group=None) -> t
         o += out_rows[r]
     flat = x.view(F * pl, C)
 
+    one_launch = _hip_rows(x, C)
+
     def step():
         all_to_all_rows(recv, flat, out_rows, in_rows, group)
-        for dst, src in pieces:
-            dst.copy_(src)
+        if one_launch:
+            from . import ops
+            ops.shard_rows(recv, out, fl, HW, C, px, False)
+        else:
+            for dst, src in pieces:
+                dst.copy_(src)
     _step(step)
     return out
 

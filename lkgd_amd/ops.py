@@ -436,6 +436,19 @@ def cfg_euler_step(noise_tokens: torch.Tensor, latents: torch.Tensor, guidance: 
     return latents
 
 
+def shard_rows(src: torch.Tensor, dst: torch.Tensor, fl: int, HW: int, C_: int, px, pack: bool) -> torch.Tensor:
+    """pack: src [fl, HW, C] -> dst rows grouped by destination pixel shard (px = pixels per shard); not pack: the inverse
+    (lkgd_shard_rows).  Both contiguous fp16."""
+    _req(src, torch.float16, "src"); _req(dst, torch.float16, "dst")
+    if not (src.is_contiguous() and dst.is_contiguous()) or src.numel() != fl * HW * C_ or dst.numel() != src.numel():
+        raise _lib.LkgdHipError("shard_rows: contiguous [fl * HW, C] buffers expected")
+    import ctypes
+    tab = (ctypes.c_int32 * len(px))(*px)
+    check(_L().lkgd_shard_rows(src.data_ptr(), dst.data_ptr(), fl, HW, C_, len(px), ctypes.cast(tab, ctypes.c_void_p), int(pack),
+                               _stream()), "lkgd_shard_rows")
+    return dst
+
+
 def tokens_to_nchw(tokens: torch.Tensor, N: int, C_: int, H: int, W: int) -> torch.Tensor:
     _req(tokens, torch.float16, "tokens")
     out = torch.empty(N, C_, H, W, dtype=torch.float16, device=tokens.device)

@@ -887,3 +887,19 @@ def test_gemm_layernorm_fold(M, N, K, res):
     with pytest.raises(LkgdHipError):
         ops.gemm(xw, torch.zeros(640, 640, dtype=torch.float16, device=DEV), torch.empty(4096, 640, dtype=torch.float16, device=DEV),
                  M=4096, N=640, K=640, ln=(torch.zeros(640, device=DEV), 1e-5))
+
+
+@pytest.mark.parametrize("fl,HW,C,px", [(4, 144, 320, (48, 32, 32, 32)), (3, 9216, 320, (2304, 2304, 2304, 2304)), (1, 7, 8, (3, 2, 2)),
+                                         (2, 576, 1280, (576,))])
+def test_shard_rows_pack_and_unpack_equal_the_strided_copies(ops, fl, HW, C, px):
+    """lkgd_shard_rows: the send buffer of frames_to_pixels (rows grouped by destination pixel shard) and its inverse, against
+    the k strided copies of lkgd_amd/dist.py"""
+    g = torch.Generator().manual_seed(fl * 1000 + HW)
+    local = torch.randn(fl, HW, C, generator=g).half().to(DEV)
+    want = torch.cat([local[:, sum(px[:r]):sum(px[:r + 1]), :].reshape(-1, C) for r in range(len(px))])
+    send = torch.full((fl * HW, C), float("nan"), dtype=torch.float16, device=DEV)
+    ops.shard_rows(local, send, fl, HW, C, px, True)
+    assert torch.equal(send, want)
+    back = torch.full((fl, HW, C), float("nan"), dtype=torch.float16, device=DEV)
+    ops.shard_rows(send, back, fl, HW, C, px, False)
+    assert torch.equal(back, local)
