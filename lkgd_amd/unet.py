@@ -822,7 +822,13 @@ class SpatioTemporalResBlock(nn.Module):
             return ops.groupnorm_silu(x, None, ctx.B, ctx.F * ctx.HW, *affine, eps)
         sums = ctx.shard.allreduce(ops.groupnorm_sums(x, None, ctx.B, ctx.F * ctx.HW))
         stats = ops.groupnorm_finalize(sums, float(ctx.F_total) * ctx.HW * (x.shape[1] // 32), eps)
-        buf = torch.zeros((ctx.F + 2) * ctx.HW, x.shape[1], dtype=torch.float16, device=x.device)
+        # (only the clip's two end slots are padding; every other halo slot is overwritten by the exchange)
+        buf = torch.empty((ctx.F + 2) * ctx.HW, x.shape[1], dtype=torch.float16, device=x.device)
+        plan = ctx.shard.plan
+        if plan.shard_index == 0:
+            buf[:ctx.HW].zero_()
+        if plan.shard_index == plan.frame_shards - 1:
+            buf[(ctx.F + 1) * ctx.HW:].zero_()
         ops.groupnorm_apply(x, None, ctx.B, ctx.F * ctx.HW, stats, *affine, True, buf[ctx.HW:(ctx.F + 1) * ctx.HW])
         return ctx.shard.halo(buf)
 
