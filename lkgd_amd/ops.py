@@ -444,8 +444,10 @@ def shard_rows(src: torch.Tensor, dst: torch.Tensor, fl: int, HW: int, C_: int, 
         raise _lib.LkgdHipError("shard_rows: contiguous [fl * HW, C] buffers expected")
     import ctypes
     tab = (ctypes.c_int32 * len(px))(*px)
-    check(_L().lkgd_shard_rows(src.data_ptr(), dst.data_ptr(), fl, HW, C_, len(px), ctypes.cast(tab, ctypes.c_void_p), int(pack),
-                               _stream()), "lkgd_shard_rows")
+    # (always the real library: this runs inside the host-side exchange steps, which a recorded plan re-runs as a whole -
+    # recording the launch as well would run it twice per replay)
+    check(_lib.lib().lkgd_shard_rows(src.data_ptr(), dst.data_ptr(), fl, HW, C_, len(px), ctypes.cast(tab, ctypes.c_void_p),
+                                     int(pack), _stream()), "lkgd_shard_rows")
     return dst
 
 
