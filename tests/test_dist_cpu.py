@@ -147,3 +147,35 @@ def test_frame_exchanges_world4():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(4))
     assert res == [(r, True) for r in range(4)]
+
+
+def test_thread_world_collectives_match_their_definitions():
+    """tests/thread_world.py (the in-process stand-in for torch.distributed the eight-rank GPU test runs on): sub-groups,
+    all-gather, all-to-all with uneven rows, all-reduce"""
+    from thread_world import ThreadWorld, run_ranks
+    W = 8
+    tw = ThreadWorld(W)
+    rows = [1, 2, 3, 1]                                   # rows every rank of a group sends to peer 0..3
+
+    def fn(r):
+        groups = [tw.new_group([0, 1, 2, 3]), tw.new_group([4, 5, 6, 7])]
+        g, si = groups[r // 4], r % 4
+        t = torch.full((2,), float(r))
+        tw.all_reduce(t, group=g)
+        buf = torch.empty(4 * 2)
+        tw.all_gather_into_tensor(buf, torch.full((2,), float(r)), group=g)
+        inp = torch.arange(7 * 2, dtype=torch.float32).reshape(7, 2) + 100 * r
+        out = torch.empty(4 * rows[si], 2)
+        tw.all_to_all_single(out, inp, [rows[si]] * 4, rows, group=g)
+        tw.barrier()
+        return t, buf, out
+
+    res = run_ranks(tw, fn)
+    for r, (t, buf, out) in enumerate(res):
+        base = 4 * (r // 4)
+        assert t.tolist() == [float(sum(range(base, base + 4)))] * 2
+        assert buf.tolist() == [float(base + i) for i in range(4) for _ in range(2)]
+        si, start = r % 4, sum(rows[:r % 4])
+        want = torch.cat([(torch.arange(14, dtype=torch.float32).reshape(7, 2) + 100 * (base + p))[start:start + rows[si]]
+                          for p in range(4)])
+        assert torch.equal(out, want)
