@@ -47,8 +47,11 @@ SPLITK_WORKSPACE_BYTES = 256 << 20
 
 
 def splitk_workspace(device) -> torch.Tensor:
-    """fp32 scratch for the split-K partial sums of few-row GEMMs; one per device: GEMMs are stream-ordered"""
-    key = (device.type, device.index)
+    """fp32 scratch for the split-K partial sums of few-row GEMMs; one per device and HOST THREAD: a GEMM and its reduce pass
+    are two launches of one C call, stream-ordered against everything this thread enqueues - but a second host thread
+    launching on the same stream could slip its own split GEMM between them (tests/thread_world.py runs ranks as threads)"""
+    import threading
+    key = (device.type, device.index, threading.get_ident())
     w = _splitk_ws.get(key)
     if w is None:
         w = torch.empty(SPLITK_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
