@@ -450,6 +450,12 @@ class Gen:
             if "nobar" in knob and i.kind in ("barrier", "waitvm", "vmem"):
                 continue
             keep.append(i)
+            # sensitivity knobs that leave the RESULT (and so the data the MFMAs see, and the clock) unchanged: every GEGLU
+            # instruction followed by a dead move / every fragment read issued twice
+            if "valupad" in knob and i.kind in ("valu", "trans") and "cost" in i.meta:
+                keep.append(Ins("v_mov_b32_e32 v%d, v%d" % (VEND - 1, VEND - 1), "valu"))
+            if "ldspad" in knob and i.kind == "lds":
+                keep.append(i)
         return " \\\n  ".join('"' + i.text + NL + '"' for i in keep)
 
     def stats(self):
