@@ -316,7 +316,7 @@ extern "C" void lkgd_debug_set_attn_waves(int nw) { attn_nw_override = nw; }
 extern "C" void lkgd_debug_set_attn_kvb(int kvb) { attn_kvb_override = kvb; }
 extern "C" void lkgd_debug_set_attn_pipe(int mode) { attn_pipe_mode = mode; }
 
-// attn_spatial_pipe.hip: two query tiles per wave, generated software-pipelined main loop; S % 128 == 0
+// attn_spatial_pipe.hip: two query tiles per wave, generated software-pipelined main loop; S >= 128
 int lkgd_attn_pipe_launch(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
                           int32_t ldo, int32_t nbatch, int32_t Sq, int32_t S, int32_t heads, const int32_t* kv_batch_map,
                           float scale, hipStream_t stream);
@@ -352,7 +352,8 @@ extern "C" int lkgd_attn_spatial_qk(const void* q, int32_t ldq, const void* k, i
   // the software-pipelined program where a workgroup's 512 queries tile the sequence well and the key loop is long enough
   // to amortise its prologue: the 72x128 level (2.74 vs 3.13 ms); at 36x64 (4.5 workgroups per image and head) the two
   // programs are equal, 0.42 ms (tools/attn_bench.py with ATTN_PIPE = 1 / 2, profiles/r04_attn_pipe_opts.txt)
-  if (attn_pipe_mode != 1 && S % 128 == 0 && !attn_nw_override && !attn_kvb_override &&
+  // (S % 128 != 0 runs the masked form of the statement: CogVideoX's 17 776 tokens)
+  if (attn_pipe_mode != 1 && S >= 128 && !attn_nw_override && !attn_kvb_override &&
       (attn_pipe_mode == 2 || (S >= 4096 && Sq >= 4096)))
     return lkgd_attn_pipe_launch(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, S, heads, kv_batch_map, scale,
                                  (hipStream_t)stream);

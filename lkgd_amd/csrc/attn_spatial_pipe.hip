@@ -8,9 +8,13 @@
 // overlap of QK^T / softmax / P.V to the chance interleaving of four waves (44.6 % matrix-pipe busy, profiles/
 // r02_pmc_attn_spatial.txt).  Workgroup = 8 waves x 64 queries = 512 queries; K / V stages of 128 keys in a three-buffer LDS
 // ring filled by LDS-DMA one stage ahead, one barrier per stage; 2 waves per SIMD (148 arch + 108 accumulation registers).
-// Used when S is a multiple of 128 (the UNet's 72x128 and 36x64 levels); everything else stays on attn_spatial.hip.
+// S % 128 != 0 (CogVideoX: 17 776 tokens) runs the MASKED form of the same statement: the last 128-key stage is loaded from
+// keys [S - 128, S) - it overlaps the stage before it by dup = 128 - S % 128 keys - and those duplicates are masked through a
+// second k-slot of the bias k-step (1.0 on the key side for exactly those rows, -30000 on the query side), so nothing is read
+// beyond the S rows of a batch entry.  Short sequences stay on attn_spatial.hip.
 #include "common.h"
 #include "attn_spatial_pipe.inc"
+#include "attn_spatial_pipe_masked.inc"     // the same program for S % 128 != 0 (ATTN_GEN_OPT=w2+mask)
 
 #define AP_NW 8
 #define AP_STAGE 32768
@@ -66,6 +70,7 @@ __device__ __forceinline__ void ap_store_tile(half_t* op, float inv, bool valid)
   });
 }
 
+template <bool MASKED>
 __global__ __launch_bounds__(AP_NW * 64, 1) __attribute__((amdgpu_num_vgpr(ATTN_PIPE_VEND))) void attn_pipe_kernel(
     const half_t* __restrict__ q, int ldq, const half_t* __restrict__ k, int ldk, const half_t* __restrict__ v, int ldv,
     half_t* __restrict__ out, int ldo, int Sq, int S, int heads, const int* __restrict__ kvmap, float scale_log2e, int nqb,
@@ -129,24 +134,43 @@ __global__ __launch_bounds__(AP_NW * 64, 1) __attribute__((amdgpu_num_vgpr(ATTN_
   const unsigned hmask = h == 0 ? 0xffffu : 0u;
 
   // ---- uniform operands: source of stage 1, its LDS destination, strides
-  const unsigned long long kp = (unsigned long long)(uintptr_t)kbase + (unsigned long long)128 * ldk * 2;
-  const unsigned long long vp = (unsigned long long)(uintptr_t)vbase + (unsigned long long)128 * ldv * 2;
+  const int nstages = MASKED ? (S + 127) / 128 : S / 128;
+  const int dup = nstages * 128 - S;                       // MASKED: keys the last stage shares with the one before it
+  const int row1 = (MASKED && nstages == 2) ? S - 128 : 128;     // first key of stage 1
+  const unsigned long long kp = (unsigned long long)(uintptr_t)kbase + (unsigned long long)row1 * ldk * 2;
+  const unsigned long long vp = (unsigned long long)(uintptr_t)vbase + (unsigned long long)row1 * ldv * 2;
   const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)kp), khi = __builtin_amdgcn_readfirstlane((unsigned)(kp >> 32));
   const unsigned vlo = __builtin_amdgcn_readfirstlane((unsigned)vp), vhi = __builtin_amdgcn_readfirstlane((unsigned)(vp >> 32));
   const unsigned dst1 = __builtin_amdgcn_readfirstlane(lds0 + AP_STAGE + w * 1024);
   const unsigned ldsend = __builtin_amdgcn_readfirstlane(lds0 + 3 * AP_STAGE);
-  const unsigned nst = __builtin_amdgcn_readfirstlane((unsigned)(S / 128));
+  const unsigned nst = __builtin_amdgcn_readfirstlane((unsigned)nstages);
   const unsigned kp1 = __builtin_amdgcn_readfirstlane((unsigned)(64 * ldk * 2)), vp1 = __builtin_amdgcn_readfirstlane((unsigned)(64 * ldv * 2));
   const unsigned kstr = __builtin_amdgcn_readfirstlane((unsigned)(128 * ldk * 2)), vstr = __builtin_amdgcn_readfirstlane((unsigned)(128 * ldv * 2));
 
   float la, lb;
-  asm volatile(ATTN_PIPE_ASM
-               : [la] "=&v"(la), [lb] "=&v"(lb), [ka0] "+v"(ka0), [ka1] "+v"(ka1), [ka2] "+v"(ka2), [ka3] "+v"(ka3),
-                 [va0] "+v"(va0), [va1] "+v"(va1)
-               : [vok] "v"(vok), [vov] "v"(vov), [xora] "v"(xora), [hmask] "v"(hmask), [klo] "s"(klo), [khi] "s"(khi),
-                 [vlo] "s"(vlo), [vhi] "s"(vhi), [dst1] "s"(dst1), [nst] "s"(nst), [kp1] "s"(kp1), [vp1] "s"(vp1),
-                 [kstr] "s"(kstr), [vstr] "s"(vstr), [ldsend] "s"(ldsend)
-               : ATTN_PIPE_CLOBBERS);
+  if constexpr (MASKED) {
+    // key row m of a 32-key tile is lane & 31; the bias k-step's A operand: 1.0 in k-slot 0 (| 1.0 in k-slot 1 on duplicate rows);
+    // its B operand carries -30000 in k-slot 1
+    const unsigned vm = (unsigned)l31, hm32 = h == 0 ? 0xffffffffu : 0u;
+    const unsigned dupk = __builtin_amdgcn_readfirstlane((unsigned)dup);
+    const unsigned klast = __builtin_amdgcn_readfirstlane((unsigned)((128 - dup) * ldk * 2));
+    const unsigned vlast = __builtin_amdgcn_readfirstlane((unsigned)((128 - dup) * ldv * 2));
+    asm volatile(ATTN_PIPEM_ASM
+                 : [la] "=&v"(la), [lb] "=&v"(lb), [ka0] "+v"(ka0), [ka1] "+v"(ka1), [ka2] "+v"(ka2), [ka3] "+v"(ka3),
+                   [va0] "+v"(va0), [va1] "+v"(va1)
+                 : [vok] "v"(vok), [vov] "v"(vov), [xora] "v"(xora), [hmask] "v"(hmask), [vm] "v"(vm), [hm32] "v"(hm32), [klo] "s"(klo), [khi] "s"(khi), [vlo] "s"(vlo), [vhi] "s"(vhi),
+                   [dst1] "s"(dst1), [nst] "s"(nst), [kp1] "s"(kp1), [vp1] "s"(vp1), [kstr] "s"(kstr), [vstr] "s"(vstr),
+                   [ldsend] "s"(ldsend), [dup] "s"(dupk), [klast] "s"(klast), [vlast] "s"(vlast)
+                 : ATTN_PIPEM_CLOBBERS);
+  } else {
+    asm volatile(ATTN_PIPE_ASM
+                 : [la] "=&v"(la), [lb] "=&v"(lb), [ka0] "+v"(ka0), [ka1] "+v"(ka1), [ka2] "+v"(ka2), [ka3] "+v"(ka3),
+                   [va0] "+v"(va0), [va1] "+v"(va1)
+                 : [vok] "v"(vok), [vov] "v"(vov), [xora] "v"(xora), [hmask] "v"(hmask), [klo] "s"(klo), [khi] "s"(khi),
+                   [vlo] "s"(vlo), [vhi] "s"(vhi), [dst1] "s"(dst1), [nst] "s"(nst), [kp1] "s"(kp1), [vp1] "s"(vp1),
+                   [kstr] "s"(kstr), [vstr] "s"(vstr), [ldsend] "s"(ldsend)
+                 : ATTN_PIPE_CLOBBERS);
+  }
 
   // ---- normalise and store.  The lane's row is re-derived from a fresh lane id so that no address register has to live
   //      across the statement (the compiler has v0..v23 there: its 14 operands and little else)
@@ -160,23 +184,30 @@ __global__ __launch_bounds__(AP_NW * 64, 1) __attribute__((amdgpu_num_vgpr(ATTN_
   ap_store_tile<ATTN_PIPE_O_B>(out + ((long long)n * Sq + rb2) * ldo + head * 64 + 4 * h2, 1.0f / lb_t, qbb < Sq);
 }
 
-// called by lkgd_attn_spatial_qk (attn_spatial.hip) after its argument checks; S % 128 == 0
+// called by lkgd_attn_spatial_qk (attn_spatial.hip) after its argument checks; S >= 128
 int lkgd_attn_pipe_launch(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
                           int32_t ldo, int32_t nbatch, int32_t Sq, int32_t S, int32_t heads, const int32_t* kv_batch_map,
                           float scale, hipStream_t stream) {
-  if (S % 128 != 0 || S < 128) return LKGD_E_SHAPE;
+  if (S < 128) return LKGD_E_SHAPE;
+  const bool masked = S % 128 != 0;        // then the last stage is keys [S - 128, S), its duplicates masked
   // the statement addresses K / V rows with 32-bit byte offsets inside a 64-row half stage
   if ((long long)64 * ldk * 2 > 0x7fffffffLL || (long long)64 * ldv * 2 > 0x7fffffffLL) return LKGD_E_SHAPE;
   LKGD_DEVICE_ONCE_BEGIN
-    if (hipFuncSetAttribute((const void*)attn_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AP_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)attn_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AP_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AP_LDS) != hipSuccess)
       return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
   const int QBLK = AP_NW * 64;
   const int nqb = (Sq + QBLK - 1) / QBLK;
   const long long nwg = (long long)nqb * nbatch * heads;
   if (nwg > 0x7fffffffLL) return LKGD_E_SHAPE;
-  hipLaunchKernelGGL(attn_pipe_kernel, dim3((unsigned)nwg), dim3(AP_NW * 64), AP_LDS, stream, (const half_t*)q, ldq,
-                     (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, Sq, S, heads, kv_batch_map,
-                     scale * 1.4426950408889634f, nqb, (int)nwg);
+  if (masked)
+    hipLaunchKernelGGL(attn_pipe_kernel<true>, dim3((unsigned)nwg), dim3(AP_NW * 64), AP_LDS, stream, (const half_t*)q, ldq,
+                       (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, Sq, S, heads, kv_batch_map,
+                       scale * 1.4426950408889634f, nqb, (int)nwg);
+  else
+    hipLaunchKernelGGL(attn_pipe_kernel<false>, dim3((unsigned)nwg), dim3(AP_NW * 64), AP_LDS, stream, (const half_t*)q, ldq,
+                       (const half_t*)k, ldk, (const half_t*)v, ldv, (half_t*)out, ldo, Sq, S, heads, kv_batch_map,
+                       scale * 1.4426950408889634f, nqb, (int)nwg);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }

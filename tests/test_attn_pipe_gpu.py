@@ -126,3 +126,60 @@ def test_pipe_is_deterministic_and_default_at_unet_levels(L):
         ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, nb, S, heads)
         outs.append(o)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+# S % 128 != 0: the masked form of the statement - the last stage is keys [S - 128, S), its overlap with the stage before it masked.
+# 129 / 255: two stages that overlap almost entirely / by one key; 200, 300: the overlap inside the first / second unit of the last
+# stage; 1000 and 2160 (= 16 x 128 + 112, CogVideoX's remainder): many stages; Sq != S; K / V are followed by NaN rows - a read
+# beyond the S keys of the last batch entry would show
+@pytest.mark.parametrize("S,Sq,heads,nb", [(129, 129, 1, 1), (255, 255, 2, 1), (200, 200, 1, 2), (300, 300, 2, 2), (448, 448, 1, 1),
+                                           (1000, 1000, 2, 2), (2160, 2160, 3, 1), (777, 100, 2, 2)])
+def test_pipe_ragged_keys_vs_fp32(L, S, Sq, heads, nb):
+    from lkgd_amd import ops
+    g = torch.Generator().manual_seed(3 * S + Sq + heads)
+    C = heads * 64
+    q = torch.randn(nb * Sq, C, generator=g).half().to(DEV)
+    kbig = torch.full((nb * S + 128, C), float("nan"), dtype=torch.float16, device=DEV)
+    vbig = torch.full((nb * S + 128, C), float("nan"), dtype=torch.float16, device=DEV)
+    kbig[:nb * S] = torch.randn(nb * S, C, generator=g).half().to(DEV)
+    vbig[:nb * S] = torch.randn(nb * S, C, generator=g).half().to(DEV)
+    k, v = kbig[:nb * S], vbig[:nb * S]
+    out = torch.full((nb * Sq, C), float("nan"), dtype=torch.float16, device=DEV)
+    try:
+        L.lkgd_debug_set_attn_pipe(2)
+        ops.attn_spatial(q, k, v, out, nb, S, heads, Sq=Sq)
+        _close(out, _ref(q, k, v, nb, heads), f"masked pipe S={S} Sq={Sq}")
+        again = torch.empty_like(out)
+        ops.attn_spatial(q, k, v, again, nb, S, heads, Sq=Sq)
+        assert torch.equal(out, again)
+        old = torch.empty_like(out)
+        L.lkgd_debug_set_attn_pipe(1)
+        ops.attn_spatial(q, k, v, old, nb, S, heads, Sq=Sq)
+        assert (out.float() - old.float()).abs().max().item() < 4e-3
+        if nb >= 2:
+            perm = torch.arange(nb).flip(0)
+            L.lkgd_debug_set_attn_pipe(2)
+            ops.attn_spatial(q, k, v, out, nb, S, heads, kv_batch_map=perm.to(torch.int32).to(DEV), Sq=Sq)
+            _close(out, _ref(q, k, v, nb, heads, perm), f"masked pipe kv-map S={S}")
+    finally:
+        L.lkgd_debug_set_attn_pipe(0)
+
+
+def test_pipe_ragged_keys_with_a_moving_reference(L):
+    """large scores in the LAST (overlapping) stage: its units are redone out of line with the same duplicate masks"""
+    from lkgd_amd import ops
+    g = torch.Generator().manual_seed(11)
+    S, C = 700, 64
+    q = torch.randn(S, C, generator=g).half()
+    k = torch.randn(S, C, generator=g).half()
+    v = torch.randn(S, C, generator=g).half()
+    k[690] = 9.0 * q[5]                     # one key far above the running reference, inside the last stage
+    k[600] = 7.0 * q[300]                   # ... and one among the masked duplicates' stage neighbours
+    q, k, v = q.to(DEV), k.to(DEV), v.to(DEV)
+    out = torch.empty(S, C, dtype=torch.float16, device=DEV)
+    try:
+        L.lkgd_debug_set_attn_pipe(2)
+        ops.attn_spatial(q, k, v, out, 1, S, 1)
+        _close(out, _ref(q, k, v, 1, 1), "masked pipe, reference moves in the last stage")
+    finally:
+        L.lkgd_debug_set_attn_pipe(0)

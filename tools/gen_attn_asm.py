@@ -60,11 +60,17 @@ BB = {"A": 100, "B": 104}
 AEND = 108
 # named SGPRs (clobbered): DMA source pointers, counters
 SK, SV, SIT, SDST, SKPOS, SVPOS, STMP, STMP2, SP1, SKD = 60, 62, 64, 65, 66, 67, 68, 69, 70, 72   # SP1 = s[70:71]
-SEND = 73
+SMASK = {"A": 73, "B": 74}     # "mask" variant: keys m of the tile's next 32-key tiles with m + 32 f < SMASK are duplicates
+STMP3 = 75
+SEND = 76 if "mask" in os.environ.get("ATTN_GEN_OPT", "w2").split("+") else 73
 STAGE = 32768
 NBUF = 3
 OPT = os.environ.get("ATTN_GEN_OPT", "w2").split("+")   # schedule options (A/B: tools/micro/attn_pipe_opts.sh)
 PSUM_LIMIT = "0x44800000"   # 1024.0
+# "mask": the variant for S % 128 != 0 (written to attn_spatial_pipe_masked.inc).  The LAST 128-key stage is loaded from keys
+# [S - 128, S): it overlaps the stage before it by dup = 128 - S % 128 keys, which are masked - a second k-slot of the bias
+# k-step carries 1.0 on the A side for exactly those key rows and -30000 on the B side - so nothing is read beyond S.
+MASKED = "mask" in OPT
 
 
 def v(n):
@@ -123,6 +129,21 @@ class Gen:
             self.e("ds_read_b64_tr_b16 %s, %%[va%d] offset:%d" % (vr(reg, 2), df, off), "lds", wr=R(reg, 2), frag=frag, nops=1)
             self.e("ds_read_b64_tr_b16 %s, %%[va%d] offset:%d" % (vr(reg + 2, 2), df, off + 1024), "lds", wr=R(reg + 2, 2),
                    frag=frag, nops=1)
+
+    def bias_mask(self, t, f, extra):
+        """mask variant: a96 <- (1.0 in k-slot 0 | 1.0 in k-slot 1 where key row m of tile f is a duplicate: m + 32 f < SMASK)"""
+        e = self.e
+        if f or extra:
+            e("s_sub_i32 s%d, s%d, %d" % (STMP3, SMASK[t], 32 * f - extra), "salu")
+        src = STMP3 if (f or extra) else SMASK[t]
+        e("v_mov_b32_e32 %s, 0x3c00" % v(MX), "valu", wr=[("v", MX)])
+        e("v_mov_b32_e32 %s, 0x3c003c00" % v(MX2), "valu", wr=[("v", MX2)])
+        e("v_cmp_gt_i32_e32 vcc, s%d, %%[vm]" % src, "valu", wr=[("vcc", 0)])
+        e("s_nop 1", "nop", n=1)       # (the previous bias MFMA has read a96 by now)
+        e("v_cndmask_b32_e32 %s, %s, %s, vcc" % (v(T0), v(MX), v(MX2)), "valu", rd=[("vcc", 0), ("v", MX), ("v", MX2)], wr=[("v", T0)])
+        e("v_and_b32_e32 %s, %%[hm32], %s" % (v(T0), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T0)])     # k-group 0 lanes only
+        e("v_accvgpr_write_b32 a%d, %s" % (ABIAS, v(T0)), "valu", rd=[("v", T0)], wr=[("a", ABIAS)])
+        e("s_nop 1", "nop", n=1)
 
     # ---- one phase -----------------------------------------------------------------------------------------------------
     def phase(self, name, sm, mm, do_qk, do_pv, ksub, vsub, prefetched, nextfrags):
@@ -208,6 +229,8 @@ class Gen:
                         self.read_frag(nextfrags[nxt - nfr], slot)
                     frn += 1
                 else:
+                    if MASKED:
+                        self.bias_mask(mm, g, 0)
                     self.e(m[0], "mfma", rd=m[2], wr=m[3], frag=None, acc=False)
             # fillers of this gap: an equal share of what is left
             lastgap = g == ngaps - 1
@@ -257,6 +280,9 @@ class Gen:
         e("v_mov_b32_e32 %s, %s" % (v(mb), v(T1)), "valu", rd=[("v", T1)], wr=[("v", mb)])
         e("v_cvt_f16_f32_e64 %s, -%s" % (v(T0), v(T1)), "valu", rd=[("v", T1)], wr=[("v", T0)])
         e("v_and_b32_e32 %s, %%[hmask], %s" % (v(T0), v(T0)), "valu", rd=[("v", T0)], wr=[("v", T0)])
+        if MASKED:
+            e("v_and_b32_e32 %s, 0xf7530000, %%[hm32]" % v(MX2), "valu", wr=[("v", MX2)])          # -30000 in k-slot 1
+            e("v_or_b32_e32 %s, %s, %s" % (v(T0), v(MX2), v(T0)), "valu", rd=[("v", T0), ("v", MX2)], wr=[("v", T0)])
         e("v_accvgpr_write_b32 a%d, %s" % (BB[t], v(T0)), "valu", rd=[("v", T0)], wr=[("a", BB[t])])
         for r in range(32):
             e("v_sub_f32_e32 %s, %s, %s" % (v(s0 + r), v(s0 + r), v(T2)), "valu", rd=[("v", s0 + r), ("v", T2)], wr=[("v", s0 + r)])
@@ -289,6 +315,9 @@ class Gen:
                   rd=[("v", T0 + ks)] if back else [], wr=R(p0 + 4 * i, 4), frag=("X",), nops=1)
             if not half:
                 for f in range(2):
+                    if MASKED:
+                        self.bias_mask(t, f, 0)
+                        self.nop(1)
                     e("v_mfma_f32_32x32x16_f16 %s, %s, %s, 0" % (vr(s0 + 16 * f, 16), ar(ABIAS, 4), ar(BB[t], 4)), "mfma",
                       rd=R(ABIAS, 4, "a") + R(BB[t], 4, "a"), wr=R(s0 + 16 * f, 16), frag=None, acc=False)
             e("s_waitcnt lgkmcnt(0)", "waitall")
@@ -333,7 +362,8 @@ class Gen:
         e("v_add_f32_e32 %s, %s, %s" % (v(L_[t]), v(L_[t]), v(PS0)), "valu", rd=[("v", L_[t]), ("v", PS0)], wr=[("v", L_[t])])
 
     # ---- DMA of one 128-key stage (this wave's four 1-KiB pieces) --------------------------------------------------------
-    def dma_stage(self):
+    def dma_stage(self, nxt_is_last):
+        """nxt_is_last (mask variant): SALU text that sets SCC = "the stage AFTER the one issued here is the last one" """
         s = self.e
         s("s_mov_b32 m0, s%d" % SDST, "salu")
         s("s_add_u32 s%d, s%d, %%[kp1]" % (SP1, SK), "salu")
@@ -350,10 +380,20 @@ class Gen:
         s("s_nop 0", "nop", n=0)
         s("global_load_lds_dwordx4 %%[vov], s[%d:%d]" % (SP1, SP1 + 1), "vmem")
         # advance the sources to the next stage, rotate the destination buffer
-        s("s_add_u32 s%d, s%d, %%[kstr]" % (SK, SK), "salu")
-        s("s_addc_u32 s%d, s%d, 0" % (SK + 1, SK + 1), "salu")
-        s("s_add_u32 s%d, s%d, %%[vstr]" % (SV, SV), "salu")
-        s("s_addc_u32 s%d, s%d, 0" % (SV + 1, SV + 1), "salu")
+        if MASKED:                    # the last stage starts at key S - 128, not at a multiple of 128
+            for t in nxt_is_last:
+                s(t, "salu")
+            s("s_cselect_b32 s%d, %%[klast], %%[kstr]" % STMP, "salu")
+            s("s_cselect_b32 s%d, %%[vlast], %%[vstr]" % STMP3, "salu")
+            s("s_add_u32 s%d, s%d, s%d" % (SK, SK, STMP), "salu")
+            s("s_addc_u32 s%d, s%d, 0" % (SK + 1, SK + 1), "salu")
+            s("s_add_u32 s%d, s%d, s%d" % (SV, SV, STMP3), "salu")
+            s("s_addc_u32 s%d, s%d, 0" % (SV + 1, SV + 1), "salu")
+        else:
+            s("s_add_u32 s%d, s%d, %%[kstr]" % (SK, SK), "salu")
+            s("s_addc_u32 s%d, s%d, 0" % (SK + 1, SK + 1), "salu")
+            s("s_add_u32 s%d, s%d, %%[vstr]" % (SV, SV), "salu")
+            s("s_addc_u32 s%d, s%d, 0" % (SV + 1, SV + 1), "salu")
         s("s_add_u32 s%d, s%d, %d" % (SDST, SDST, STAGE), "salu")
         s("s_sub_u32 s%d, s%d, %d" % (STMP, SDST, NBUF * STAGE), "salu")
         s("s_cmp_ge_u32 s%d, %%[ldsend]" % SDST, "salu")
@@ -399,6 +439,9 @@ class Gen:
             s("v_mov_b32_e32 %s, 0" % v(L_[t]), "valu", wr=[("v", L_[t])])
             s("v_mov_b32_e32 %s, 0" % v(MB[t]), "valu", wr=[("v", MB[t])])
         s("s_mov_b32 s%d, 0" % SKD, "salu")
+        if MASKED:                                    # (at least two stages: stage 0 is never the last one)
+            s("s_mov_b32 s%d, 0" % SMASK["A"], "salu")
+            s("s_mov_b32 s%d, 0" % SMASK["B"], "salu")
         self.ckpt()                                   # 2: after the register initialisation
         # ---- stage 0 has been issued by the kernel; publish it, start stage 1
         s("s_waitcnt vmcnt(0)", "waitvm")
@@ -406,7 +449,7 @@ class Gen:
         self.ckpt()                                   # 3: after the first barrier
         s("s_cmp_lt_u32 1, %[nst]", "salu")
         s("s_cbranch_scc0 NOST1_%=", "branch", target="NOST1")
-        self.dma_stage()
+        self.dma_stage(["s_cmp_eq_u32 %[nst], 3"])    # stage 1 issued here; stage 2 is the last one iff nst == 3
         self.label("NOST1")
         self.ckpt()                                   # 4: after the DMA of stage 1
         # ---- P0: QK_A(0), first reference of A.  P1 = alpha(0): sm_A(0) | QK_B(0), first reference of B
@@ -421,10 +464,14 @@ class Gen:
         # ---- loop over stages.  boundary(tile, tag, back, ksub): where the K sub-tile of the unit just exponentiated lives
         self.label("LOOP")
         self.ckpt()                                   # 8
+        if MASKED:                                    # second unit of a stage: 64 keys further
+            s("s_sub_i32 s%d, s%d, 64" % (SMASK["A"], SMASK["A"]), "salu")
         self.phase("beta(2s)", "B", "A", True, True, 1, 0, True, K(1))
         self.ckpt()                                   # 9
         self.boundary("B", "0", False, 0, slow)
         self.ckpt()                                   # 10
+        if MASKED:
+            s("s_sub_i32 s%d, s%d, 64" % (SMASK["B"], SMASK["B"]), "salu")
         self.phase("alpha(2s+1)", "A", "B", True, True, 1, 0, True, None)
         self.boundary("A", "1", False, 1, slow)
         self.ckpt()                                   # 11
@@ -436,11 +483,17 @@ class Gen:
         s("s_add_u32 s%d, s%d, 2" % (STMP2, SIT), "salu")
         s("s_cmp_lt_u32 s%d, %%[nst]" % STMP2, "salu")
         s("s_cbranch_scc0 NODMA_%=", "branch", target="NODMA")
-        self.dma_stage()
+        self.dma_stage(["s_add_u32 s%d, s%d, 4" % (STMP2, SIT), "s_cmp_eq_u32 s%d, %%[nst]" % STMP2])   # stage s+2 issued; s+3 last?
         self.label("NODMA")
         self.advance(SKPOS, ["ka0", "ka1", "ka2", "ka3"], SKD)
+        if MASKED:                                    # first unit of stage s+1: the last stage starts with dup duplicates
+            s("s_add_u32 s%d, s%d, 2" % (STMP2, SIT), "salu")
+            s("s_cmp_eq_u32 s%d, %%[nst]" % STMP2, "salu")
+            s("s_cselect_b32 s%d, %%[dup], 0" % SMASK["A"], "salu")
         self.phase("beta(2s+1)", "B", "A", True, True, 0, 1, False, K(0))
         self.boundary("B", "2", True, 1, slow)        # B(2s+1): K of stage s, the addresses are at stage s+1
+        if MASKED:
+            s("s_mov_b32 s%d, s%d" % (SMASK["B"], SMASK["A"]), "salu")
         self.phase("alpha(2s+2)", "A", "B", True, True, 0, 1, True, K(1))
         self.boundary("A", "3", False, 0, slow)
         self.advance(SVPOS, ["va0", "va1"], None)
@@ -644,16 +697,19 @@ def main():
     g.check()
     if "--stats" in sys.argv:
         g.stats()
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lkgd_amd", "csrc", "attn_spatial_pipe.inc")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lkgd_amd", "csrc",
+                       "attn_spatial_pipe_masked.inc" if MASKED else "attn_spatial_pipe.inc")
+    P = "ATTN_PIPEM" if MASKED else "ATTN_PIPE"
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py - do not edit.  Main loop of attn_spatial_pipe.hip (register plan and\n"
                 "// schedule: see that script).\n")
-        f.write("#define ATTN_PIPE_VB %d\n#define ATTN_PIPE_VEND %d\n#define ATTN_PIPE_AEND %d\n" % (VB, VEND, AEND))
-        f.write("#define ATTN_PIPE_QF_A %d\n#define ATTN_PIPE_QF_B %d\n#define ATTN_PIPE_O_A %d\n#define ATTN_PIPE_O_B %d\n"
-                % (QF["A"], QF["B"], OACC["A"], OACC["B"]))
-        f.write("#define ATTN_PIPE_ASM \\\n  %s\n\n" % g.text())
+        if not MASKED:
+            f.write("#define ATTN_PIPE_VB %d\n#define ATTN_PIPE_VEND %d\n#define ATTN_PIPE_AEND %d\n" % (VB, VEND, AEND))
+            f.write("#define ATTN_PIPE_QF_A %d\n#define ATTN_PIPE_QF_B %d\n#define ATTN_PIPE_O_A %d\n#define ATTN_PIPE_O_B %d\n"
+                    % (QF["A"], QF["B"], OACC["A"], OACC["B"]))
+        f.write("#define %s_ASM \\\n  %s\n\n" % (P, g.text()))
         clob = ['"v%d"' % i for i in range(VB, VEND)] + ['"a%d"' % i for i in range(AEND)] + ['"s%d"' % i for i in range(SK, SEND)]
-        f.write("#define ATTN_PIPE_CLOBBERS " + ", ".join(clob) + ', "vcc", "scc", "m0", "memory"\n')
+        f.write("#define %s_CLOBBERS " % P + ", ".join(clob) + ', "vcc", "scc", "m0", "memory"\n')
     print("wrote", out)
 
 
