@@ -415,7 +415,7 @@ const char* lkgd_version(void);
  *      lkgd_debug_set_attn_waves(nw)    spatial attention: waves per workgroup (4 / 8 / 16); 0 = by sequence length
  *      lkgd_debug_set_attn_kvb(kvb)     spatial attention: keys per barrier (64 / 128); 0 = default
  *      lkgd_debug_set_attn_pipe(mode)   spatial attention: 1 = never the software-pipelined program (attn_spatial_pipe.hip),
- *                                       2 = wherever it is legal (S a multiple of 128); 0 = by sequence length
+ *                                       2 = wherever it is legal (S >= 128; S % 128 != 0 runs its masked form); 0 = by sequence length
  *      lkgd_debug_set_gn_apply_kb(kb) / lkgd_debug_set_gn_stats_kb(kb)   GroupNorm chunk sizes in KiB (>= 32)
  * ------------------------------------------------------------------------------------------------------------- */
 void lkgd_debug_set_gemm_variant(int32_t v);
