@@ -8,8 +8,6 @@ launch on the same (default) stream, so a peer's tensor deposited before a barri
 another thread's copy of it is enqueued after the barrier.  Reductions add in group-rank order (deterministic)."""
 import threading
 
-import torch
-
 
 class _Group:
     def __init__(self, ranks):
