@@ -551,15 +551,17 @@ class TemporalBasicTransformerBlock(nn.Module):
         va = None
         # LayerNorm + QKV + attention over the frames in one kernel where it exists (C = 320: the 72x128 level); the joint
         # branch reads the normalised tokens again, masked LoRA runs per-entry weights, a sharded rank gathers frames: unfused
-        fused = (ctx.lora is None and not ctx.frames_sharded and ops.tattn_front_ok(Cc, self.attn1.heads, ctx.F, ctx.HW) and
-                 not (self.enable_joint_attention and hasattr(self, "attn1n")))
+        joint = self.enable_joint_attention and hasattr(self, "attn1n")
+        base_ok = ctx.lora is None and not ctx.frames_sharded and ops.tattn_front_ok(Cc, self.attn1.heads, ctx.F, ctx.HW)
+        fused = base_ok and not joint
         from . import dist as _dist
         # (a level with fewer pixels than shards - the 1x1 level of the tiny test nets - keeps the gathered form)
         resharded = (ctx.frames_sharded and ctx.lora is None and not _dist.TEMPORAL_GATHER and
                      ctx.HW >= ctx.shard.plan.frame_shards)
-        ln1 = None if (fused or resharded) else ops.layernorm(m1, None, None, 1e-5)
-        # ... and the out-projection, its residual and the folded cross-attention table in the same launch (attn_tblock.hip)
-        one_launch = fused and ops.tattn_block_ok(Cc, self.attn1.heads, ctx.F, ctx.HW)
+        # ... and the out-projection, its residual and the folded cross-attention table in the same launch (attn_tblock.hip);
+        # with the joint branch on, the main branch still runs that way and only the joint branch's input is normalised apart
+        one_launch = base_ok and ops.tattn_block_ok(Cc, self.attn1.heads, ctx.F, ctx.HW)
+        ln1 = None if ((fused or resharded or one_launch) and not (one_launch and joint)) else ops.layernorm(m1, None, None, 1e-5)
         if one_launch:
             pass
         elif fused:

@@ -194,6 +194,17 @@ def test_full_size_lk_joint_and_fsm_hook_properties():
     a = run()
     assert torch.isfinite(a.float()).all() and torch.equal(a, run())
     print(f"joint hooks with weights vs no hooks: rel L2 {_rel(a, base):.3e}")
+    # with the temporal joint branch on, the main temporal attention still runs as the one-launch kernel (the joint branch gets
+    # its own LayerNorm pass): same result as the unfused chain the tiny-width goldens pin, to fp16 noise
+    from lkgd_amd import ops as _ops
+    was = _ops.TBLOCK
+    try:
+        _ops.TBLOCK = False
+        chain = run()
+    finally:
+        _ops.TBLOCK = was
+    print(f"one-launch temporal attention vs the unfused chain, joint hooks on: rel L2 {_rel(a, chain):.3e}")
+    assert _rel(a, chain) < 5e-3
     assert _rel(a, base) > max(2e-2, 4 * noise)           # the partner clip reaches the result
     # (set_joint_attention(False) would not last - the loop switches the hooks on at every step, pipeline_..._trans.py:555 -
     # and joint_scale only reaches the spatial branch, patch.py:500 vs :654: removing the patch is what restores the model)
