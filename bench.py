@@ -466,7 +466,7 @@ def main():
         sampled = len([i for i in range(args.inference_steps) if i % runner.event_stride == runner.event_stride // 2]) \
             if distributed else args.inference_steps
         scale = args.inference_steps / max(sampled, 1)
-        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_{wide,resw,rowpanel,stream}_kernel + lkgd_gemm_kernel + ff_fused_kernel + tattn_block_kernel (MFMA GEMM / implicit-conv family; the two fused kernels count the flop of their matrix products)",
+        roofline = {"bound": "mfma", "kernel": "lkgd_gemm_{wide,resw,rowpanel,stream}_kernel + lkgd_gemm_kernel + ff_fused_kernel + tattn_block_kernel + ln_qkv_kernel (MFMA GEMM / implicit-conv family; the fused kernels count the flop of their matrix products)",
                     "achieved": round(achieved, 2),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches": len(events),

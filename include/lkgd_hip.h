@@ -177,6 +177,17 @@ int lkgd_tattn_block_c320(const void* x, int32_t ldx, const void* wstream, const
                           int32_t B, int32_t F, int32_t HW, float eps, lkgd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * 3c. LayerNorm + a 320 -> 960 projection in one launch (the 72x128 level):  out[T, 960] = W . LN(x) + b,  LN without affine
+ *    (folded into W / b when the stream is packed), fp32 accumulation, fp16 in / out; the normalised rows are never written.
+ *    wstream: the chunk stream lkgd_amd/packing.py::pack_ln_proj builds (30 tiles of 32 output rows: bias fragment + 20 k-step
+ *    fragments, 645 120 bytes).  ldo % 8 == 0, out 16-byte aligned.
+ *    Replaces: BasicTransformerBlock `norm1` + `attn1.to_q / to_k / to_v` as one fused [3C, C] projection
+ *    (patch/patch.py:416, :440-445; [EXT] diffusers Attention).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_ln_qkv_c320(const void* x, int32_t ldx, int64_t T, const void* wstream, float eps, void* out, int32_t ldo,
+                     lkgd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * 3b. LayerNorm + GEGLU feed-forward + output projection + residual(s) in one launch, C = 320 / inner 1280 (the 72x128
  *    level).  x' = x + rowbias[idx(row)] (idx = (row / rb_d1) % rb_md; rowbias may be NULL);
  *        out = s_acc * ( W2 . ( hidden * gelu(gate) ) + b2 + x' ) + r2 * res2,   [hidden | gate] = W1 . LN(x') + b1

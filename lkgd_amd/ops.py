@@ -277,6 +277,31 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
 FF_FUSED = os.environ.get("LKGD_NO_FF_FUSED", "0") != "1"
 
 
+#: A/B switch of the one-launch LayerNorm + QKV projection of the 72x128 level (False = the row-panel GEMM with the LayerNorm fold)
+LN_QKV = os.environ.get("LKGD_NO_LN_QKV", "0") != "1"
+
+
+def ln_qkv_ok(T: int, N: int, C_: int) -> bool:
+    """the fused kernel exists for 320 -> 960 and pays where its 128-token panels fill the CUs several times over"""
+    return LN_QKV and C_ == 320 and N == 960 and T >= 60000
+
+
+def ln_qkv(x: torch.Tensor, wstream: torch.Tensor, out: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """out[T, 960] = W . LN(x) + b in one launch (lkgd_ln_qkv_c320)"""
+    _req(x, torch.float16, "x"); _req(wstream, torch.float16, "wstream"); _req(out, torch.float16, "out")
+    T = x.shape[0]
+    ev = GEMM_EVENTS
+    if ev is not None:
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+    check(_L().lkgd_ln_qkv_c320(x.data_ptr(), _ld(x), T, wstream.data_ptr(), eps, out.data_ptr(), _ld(out), _stream()),
+          "lkgd_ln_qkv_c320")
+    if ev is not None:
+        e_ev.record()
+        ev.append((s_ev, e_ev, 2.0 * T * 960 * 320))
+    return out
+
+
 def ff_fused_ok(C_: int, inner: int) -> bool:
     return FF_FUSED and C_ == 320 and inner == 1280
 

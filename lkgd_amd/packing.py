@@ -88,6 +88,25 @@ def pack_tblock(wqkv: torch.Tensor, bqkv, wo: torch.Tensor, heads: int = 5) -> t
     return out
 
 
+def pack_ln_proj(w: torch.Tensor, b) -> torch.Tensor:
+    """Chunk stream of lkgd_ln_qkv_c320 (lkgd_amd/csrc/qkv_fused.hip, tools/gen_qkv_asm.py): w [960, 320] (LayerNorm affine folded
+    in), b [960] or None.  Returns fp16 [n] = 30 chunks, one per 32 output rows: 21 MFMA A fragments of 64 lanes x 8 halfs (lane =
+    32 hh + row): fragment 0 the bias as (b_hi, b_lo) in k-slots 0, 1 of the hh = 0 lanes, fragments 1..20 w[32 t + row][16 ks +
+    8 hh + e]."""
+    assert w.shape == (960, 320)
+    dev = w.device
+    wh = w.to(torch.float16).reshape(30, 32, 20, 2, 8)                      # [tile, row, ks, hh, e]
+    bf = (b if b is not None else torch.zeros(960, device=dev)).to(torch.float32).reshape(30, 32)
+    b_hi = bf.to(torch.float16)
+    b_lo = (bf - b_hi.to(torch.float32)).to(torch.float16)
+    bias = torch.zeros(30, 2, 32, 8, dtype=torch.float16, device=dev)
+    bias[:, 0, :, 0], bias[:, 0, :, 1] = b_hi, b_lo
+    body = wh.permute(0, 2, 3, 1, 4)                                        # [tile, ks, hh, row, e]
+    out = torch.cat([bias.reshape(30, 1, -1), body.reshape(30, 20, -1)], dim=1).reshape(-1).contiguous()
+    assert out.numel() * 2 == 30 * 21504
+    return out
+
+
 def geglu_perm(inner: int, half: int = 32, device=None) -> torch.Tensor:
     """row permutation of the GEGLU projection [2*inner, K]: every 2*half packed rows = `half` hidden rows followed by
     their `half` gate rows (inner + ..), so that the output columns one wave owns hold both factors of its GEGLU

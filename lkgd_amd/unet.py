@@ -408,7 +408,12 @@ class BasicTransformerBlock(nn.Module):
                 not (self.enable_joint_attention and hasattr(self, "attn1n")))
         ln = None if fold else ops.layernorm(h, None, None, 1e-5)
         qkv = ctx.new(T, 3 * Cc)
-        if fold:
+        if fold and ops.ln_qkv_ok(T, 3 * Cc, Cc):       # LayerNorm + Q|K|V in one launch of the fused-kernel skeleton (qkv_fused.hip)
+            if getattr(pk.a1, "wlnqkv", None) is None:
+                from .packing import pack_ln_proj
+                pk.a1.wlnqkv = pack_ln_proj(pk.a1.wqkv, pk.a1.bqkv)
+            ops.ln_qkv(h, pk.a1.wlnqkv, qkv)
+        elif fold:
             ops.gemm(h, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv, ln=(pk.a1.cs, 1e-5))
         elif ctx.lora is None:
             ops.gemm(ln, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)

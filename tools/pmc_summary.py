@@ -45,7 +45,7 @@ def main(fetch_csv, write_csv, json_out=None):
 
     if json_out:
         import json
-        fam = {k: v for k, v in fe.items() if "lkgd_gemm" in k or "ff_fused" in k or "tattn_block" in k}      # what ops.GEMM_EVENTS times
+        fam = {k: v for k, v in fe.items() if "lkgd_gemm" in k or "ff_fused" in k or "tattn_block" in k or "ln_qkv" in k}      # what ops.GEMM_EVENTS times
         launches = sum(v[0] for v in fam.values())
         total = sum(v[1] * 1024 * 2 for v in fam.values()) + sum(wr.get(k, [0, 0.0, 0.0])[1] * 1024 for k in fam)
         doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 0 "
