@@ -186,6 +186,10 @@ int lkgd_tattn_block_c320(const void* x, int32_t ldx, const void* wstream, const
  * ------------------------------------------------------------------------------------------------------------- */
 int lkgd_ln_qkv_c320(const void* x, int32_t ldx, int64_t T, const void* wstream, float eps, void* out, int32_t ldo,
                      lkgd_stream_t stream);
+/* the same at the 36x64 level: 640 -> 1920 (60 tiles of 32 output rows, each a 21-KiB chunk (bias fragment + k-steps 0..19) and a
+ * 20-KiB chunk (k-steps 20..39): 2 519 040 bytes from pack_ln_proj); also norm1 -> to_q | to_k | to_v of the temporal blocks there */
+int lkgd_ln_qkv_c640(const void* x, int32_t ldx, int64_t T, const void* wstream, float eps, void* out, int32_t ldo,
+                     lkgd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 3b. LayerNorm + GEGLU feed-forward + output projection + residual(s) in one launch, C = 320 / inner 1280 (the 72x128

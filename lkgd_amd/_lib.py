@@ -70,6 +70,7 @@ SYMBOLS = {
                               _vp]),
     "lkgd_tattn_block_c320": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "lkgd_ln_qkv_c320": (_i32, [_vp, _i32, _i64, _vp, _f32, _vp, _i32, _vp]),
+    "lkgd_ln_qkv_c640": (_i32, [_vp, _i32, _i64, _vp, _f32, _vp, _i32, _vp]),
     "lkgd_ff_fused_c320": (_i32, [_vp, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _i32, _f32, _vp, _i32, _vp]),
     "lkgd_attn_spatial": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),
     "lkgd_attn_spatial_qk": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),

@@ -282,23 +282,25 @@ LN_QKV = os.environ.get("LKGD_NO_LN_QKV", "0") != "1"
 
 
 def ln_qkv_ok(T: int, N: int, C_: int) -> bool:
-    """the fused kernel exists for 320 -> 960 and pays where its 128-token panels fill the CUs several times over"""
-    return LN_QKV and C_ == 320 and N == 960 and T >= 60000
+    """the fused kernel exists for 320 -> 960 and 640 -> 1920 and pays where its 128-token panels fill the CUs (about) twice over"""
+    return LN_QKV and C_ in (320, 640) and N == 3 * C_ and T >= 60000
 
 
 def ln_qkv(x: torch.Tensor, wstream: torch.Tensor, out: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """out[T, 960] = W . LN(x) + b in one launch (lkgd_ln_qkv_c320)"""
+    """out[T, 3C] = W . LN(x) + b in one launch (lkgd_ln_qkv_c320 / _c640 by x's width)"""
     _req(x, torch.float16, "x"); _req(wstream, torch.float16, "wstream"); _req(out, torch.float16, "out")
-    T = x.shape[0]
+    T, C_ = x.shape
+    if C_ not in (320, 640):
+        raise _lib.LkgdHipError("ln_qkv: 320 or 640 channels")
+    fn = _L().lkgd_ln_qkv_c320 if C_ == 320 else _L().lkgd_ln_qkv_c640
     ev = GEMM_EVENTS
     if ev is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s_ev.record()
-    check(_L().lkgd_ln_qkv_c320(x.data_ptr(), _ld(x), T, wstream.data_ptr(), eps, out.data_ptr(), _ld(out), _stream()),
-          "lkgd_ln_qkv_c320")
+    check(fn(x.data_ptr(), _ld(x), T, wstream.data_ptr(), eps, out.data_ptr(), _ld(out), _stream()), "lkgd_ln_qkv")
     if ev is not None:
         e_ev.record()
-        ev.append((s_ev, e_ev, 2.0 * T * 960 * 320))
+        ev.append((s_ev, e_ev, 2.0 * T * 3 * C_ * C_))
     return out
 
 

@@ -89,21 +89,23 @@ def pack_tblock(wqkv: torch.Tensor, bqkv, wo: torch.Tensor, heads: int = 5) -> t
 
 
 def pack_ln_proj(w: torch.Tensor, b) -> torch.Tensor:
-    """Chunk stream of lkgd_ln_qkv_c320 (lkgd_amd/csrc/qkv_fused.hip, tools/gen_qkv_asm.py): w [960, 320] (LayerNorm affine folded
-    in), b [960] or None.  Returns fp16 [n] = 30 chunks, one per 32 output rows: 21 MFMA A fragments of 64 lanes x 8 halfs (lane =
-    32 hh + row): fragment 0 the bias as (b_hi, b_lo) in k-slots 0, 1 of the hh = 0 lanes, fragments 1..20 w[32 t + row][16 ks +
-    8 hh + e]."""
-    assert w.shape == (960, 320)
+    """Chunk stream of lkgd_ln_qkv_c320 / _c640 (lkgd_amd/csrc/qkv_fused.hip, tools/gen_qkv_asm.py): w [3C, C] (LayerNorm affine
+    folded in), b [3C] or None, C = 320 or 640.  Returns fp16 [n]: per 32 output rows (a tile) C / 320 chunks - the first one 21 MFMA
+    A fragments of 64 lanes x 8 halfs (lane = 32 hh + row): fragment 0 the bias as (b_hi, b_lo) in k-slots 0, 1 of the hh = 0 lanes,
+    then k-steps 0..19: w[32 t + row][16 ks + 8 hh + e]; a second chunk (C = 640) k-steps 20..39."""
+    n_out, c = w.shape
+    assert c in (320, 640) and n_out == 3 * c
     dev = w.device
-    wh = w.to(torch.float16).reshape(30, 32, 20, 2, 8)                      # [tile, row, ks, hh, e]
-    bf = (b if b is not None else torch.zeros(960, device=dev)).to(torch.float32).reshape(30, 32)
+    tiles, nks = n_out // 32, c // 16
+    wh = w.to(torch.float16).reshape(tiles, 32, nks, 2, 8)                  # [tile, row, ks, hh, e]
+    bf = (b if b is not None else torch.zeros(n_out, device=dev)).to(torch.float32).reshape(tiles, 32)
     b_hi = bf.to(torch.float16)
     b_lo = (bf - b_hi.to(torch.float32)).to(torch.float16)
-    bias = torch.zeros(30, 2, 32, 8, dtype=torch.float16, device=dev)
+    bias = torch.zeros(tiles, 2, 32, 8, dtype=torch.float16, device=dev)
     bias[:, 0, :, 0], bias[:, 0, :, 1] = b_hi, b_lo
-    body = wh.permute(0, 2, 3, 1, 4)                                        # [tile, ks, hh, row, e]
-    out = torch.cat([bias.reshape(30, 1, -1), body.reshape(30, 20, -1)], dim=1).reshape(-1).contiguous()
-    assert out.numel() * 2 == 30 * 21504
+    body = wh.permute(0, 2, 3, 1, 4).reshape(tiles, nks, -1)                # [tile, ks, (hh, row, e)]
+    out = torch.cat([bias.reshape(tiles, 1, -1), body], dim=1).reshape(-1).contiguous()    # bias | ks 0..nks-1 per tile
+    assert out.numel() * 2 == tiles * (21504 + (nks // 20 - 1) * 20480)
     return out
 
 

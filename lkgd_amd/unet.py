@@ -404,11 +404,13 @@ class BasicTransformerBlock(nn.Module):
         heads = self.attn1.heads
         # norm1 folded into the QKV projection where the row-panel program runs it (K = 320 at many rows): the normalised
         # tokens are never written; the joint branch reads them again and keeps the LayerNorm pass
-        fold = (ctx.lora is None and pk.a1.cs is not None and ops.gemm_ln_ok(T, 3 * Cc, Cc) and
-                not (self.enable_joint_attention and hasattr(self, "attn1n")))
-        ln = None if fold else ops.layernorm(h, None, None, 1e-5)
+        joint = self.enable_joint_attention and hasattr(self, "attn1n")
+        fold = ctx.lora is None and pk.a1.cs is not None and ops.gemm_ln_ok(T, 3 * Cc, Cc) and not joint
+        # LayerNorm + Q|K|V in one launch of the fused-kernel skeleton (qkv_fused.hip: the 72x128 and 36x64 levels)
+        one = ctx.lora is None and not joint and ops.ln_qkv_ok(T, 3 * Cc, Cc)
+        ln = None if (fold or one) else ops.layernorm(h, None, None, 1e-5)
         qkv = ctx.new(T, 3 * Cc)
-        if fold and ops.ln_qkv_ok(T, 3 * Cc, Cc):       # LayerNorm + Q|K|V in one launch of the fused-kernel skeleton (qkv_fused.hip)
+        if one:
             if getattr(pk.a1, "wlnqkv", None) is None:
                 from .packing import pack_ln_proj
                 pk.a1.wlnqkv = pack_ln_proj(pk.a1.wqkv, pk.a1.bqkv)
@@ -566,7 +568,11 @@ class TemporalBasicTransformerBlock(nn.Module):
         # ... and the out-projection, its residual and the folded cross-attention table in the same launch (attn_tblock.hip);
         # with the joint branch on, the main branch still runs that way and only the joint branch's input is normalised apart
         one_launch = base_ok and ops.tattn_block_ok(Cc, self.attn1.heads, ctx.F, ctx.HW)
-        ln1 = None if ((fused or resharded or one_launch) and not (one_launch and joint)) else ops.layernorm(m1, None, None, 1e-5)
+        # (the 36x64 level: LayerNorm + Q|K|V in one launch, then the attention kernel)
+        ln_qkv_one = (not (fused or resharded or one_launch) and ctx.lora is None and not ctx.frames_sharded and not joint and
+                      ops.ln_qkv_ok(T, 3 * Cc, Cc))
+        ln1 = None if (((fused or resharded or one_launch) and not (one_launch and joint)) or ln_qkv_one) else \
+            ops.layernorm(m1, None, None, 1e-5)
         if one_launch:
             pass
         elif fused:
@@ -584,7 +590,13 @@ class TemporalBasicTransformerBlock(nn.Module):
                               self.attn1.heads)
         elif not ctx.frames_sharded:
             qkv = ctx.new(T, 3 * Cc)
-            ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
+            if ln_qkv_one:
+                if getattr(pk.a1, "wlnqkv", None) is None:
+                    from .packing import pack_ln_proj
+                    pk.a1.wlnqkv = pack_ln_proj(pk.a1.wqkv, pk.a1.bqkv)
+                ops.ln_qkv(m1, pk.a1.wlnqkv, qkv)
+            else:
+                ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
             ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
                               self.attn1.heads)
         elif resharded:

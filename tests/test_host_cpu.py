@@ -264,7 +264,7 @@ def test_resident_weight_kernel_has_no_register_spills():
 
 
 @pytest.mark.parametrize("src,kernel,agprs", [("ff_fused.hip", "ff_fused_kernel", 244), ("attn_spatial_pipe.hip", "attn_pipe_kernel", 108),
-                                              ("attn_tblock.hip", "tattn_block_kernel", 244), ("qkv_fused.hip", "ln_qkv_kernel", 84)])
+                                              ("attn_tblock.hip", "tattn_block_kernel", 244), ("qkv_fused.hip", "ln_qkv_kernel", (84, 164))])
 def test_generated_loop_kernels_keep_their_accumulation_registers(src, kernel, agprs, tmp_path):
     """ff_fused.hip / attn_spatial_pipe.hip keep state in accumulation registers ACROSS their asm statements (Y^T and z^T; Q and
     O), which the compiler knows nothing about: it must never place values of its own there.  Checked on the ISA: every
@@ -285,7 +285,8 @@ def test_generated_loop_kernels_keep_their_accumulation_registers(src, kernel, a
     assert kernel in text
     counts = [int(v) for v in re.findall(r"; NumAgprs: (\d+)", text)]
     scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
-    assert counts and all(c == agprs for c in counts), counts
+    want = agprs if isinstance(agprs, tuple) else (agprs,)
+    assert counts and sorted(set(counts)) == sorted(want), counts
     assert all(s == 0 for s in scratch), scratch
     inside, bad = False, []
     for line in text.splitlines():

@@ -27,15 +27,20 @@ NRING = 8
 RING = VB + 48
 TMP = RING + 4 * NRING
 VEND = TMP + 2
-ZF, ONESB, AEND = 0, 80, 84
-NKS = 20
-W1_FR = NKS + 1
+C_IN = int(os.environ.get("QKV_GEN_C", "320"))      # 320 (30 tiles, the 72x128 level) or 640 (60 tiles, the 36x64 level)
+assert C_IN in (320, 640)
+NKS = C_IN // 16
+PARTS = NKS // 20         # chunks per tile: a chunk is the bias fragment + 20 k-steps, or 20 further k-steps (<= 21 KiB)
+ZF, ONESB, AEND = 0, 4 * NKS, 4 * NKS + 4
+W1_FR = 21
 W1_BYTES = W1_FR * 1024
+W2_BYTES = 20 * 1024
 SLOT = 24576
 AHEAD = int(os.environ.get("QKV_GEN_AHEAD", "3"))      # chunks in flight ahead of the one that becomes visible
 NSLOT = AHEAD + 2
 WAITN = 4
-NTILE = 30                # 960 output channels
+NTILE = 3 * C_IN // 32    # 3 C output channels
+NCH = NTILE * PARTS
 RATE = 2
 SP = 68                   # s[68:69]: the weight stream pointer
 
@@ -134,16 +139,18 @@ class Gen:
 
     def dma_items(self, chunk, wrap):
         slot = chunk % NSLOT
+        first = chunk % PARTS == 0           # the chunk that opens a tile carries the bias fragment (a 21st KiB)
         it = []
         for j in range(5):
             it.append(("s_add_u32 m0, %%[ldsw], %d" % (slot * SLOT + j * 4096),
                        "global_load_lds_dwordx4 %%[vo%d], s[%d:%d]" % (j, SP, SP + 1)))
-        it.append(("s_add_u32 m0, %%[lds0], %d" % (slot * SLOT + 20480),
-                   "global_load_lds_dwordx4 %%[vob], s[%d:%d]" % (SP, SP + 1)))
+        if first:
+            it.append(("s_add_u32 m0, %%[lds0], %d" % (slot * SLOT + 20480),
+                       "global_load_lds_dwordx4 %%[vob], s[%d:%d]" % (SP, SP + 1)))
         if wrap:
             it.append(("s_mov_b32 s%d, %%[sp0lo]" % SP, "s_mov_b32 s%d, %%[sp0hi]" % (SP + 1)))
         else:
-            it.append(("s_add_u32 s%d, s%d, %d" % (SP, SP, W1_BYTES), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1)))
+            it.append(("s_add_u32 s%d, s%d, %d" % (SP, SP, W1_BYTES if first else W2_BYTES), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1)))
         self.dma_chunk = chunk
         return it
 
@@ -167,37 +174,39 @@ class Gen:
             self.nop(0)
             self.dma_second()
 
-    # ---- one chunk = one 32-channel output tile -----------------------------------------------------------------------------
-    def chunk(self, n):
-        self.e("; ---- tile %d" % n, "comment")
-        nfr, slot = W1_FR, n % NSLOT
-        last = n == NTILE - 1
-        tags = [(n, i) for i in range(nfr)]
+    # ---- one chunk = (part of) one 32-channel output tile ---------------------------------------------------------------------
+    def chunk(self, c):
+        n, part = divmod(c, PARTS)
+        self.e("; ---- tile %d part %d" % (n, part), "comment")
+        nfr, slot = (W1_FR if part == 0 else 20), c % NSLOT
+        last = c == NCH - 1
+        tags = [(c, i) for i in range(nfr)]
         d = ACC[n & 1]
-        for it in self.queue:       # the accumulator set of tile n - 2 must have been converted
-            if isinstance(it, Ins):
-                assert not (set(R(d, 16)) & set(it.rd)), ("tile %d overwrites accumulators still to be converted" % n, it.text)
+        if part == 0:
+            for it in self.queue:       # the accumulator set of tile n - 2 must have been converted
+                if isinstance(it, Ins):
+                    assert not (set(R(d, 16)) & set(it.rd)), ("tile %d overwrites accumulators still to be converted" % n, it.text)
         for i in range(nfr):
             if i == nfr - NRING and not last:
                 assert not self.pending_dma, "the previous chunk's DMA is still being issued"
-                # chunk n + 1 becomes visible: own pieces landed (whatever was issued behind them may stay in flight)
-                wait_n = self.vm_after(n + 1)
+                # chunk c + 1 becomes visible: own pieces landed (whatever was issued behind them may stay in flight)
+                wait_n = self.vm_after(c + 1)
                 assert wait_n <= 63, wait_n
                 self.e("s_waitcnt vmcnt(%d)" % wait_n, "waitvm")
                 self.e("s_barrier", "barrier")
-                pre = n + 1 + AHEAD              # the next panel's first chunks from the last tiles on
-                self.pending_dma = self.dma_items(pre, wrap=(pre % NTILE == NTILE - 1))
+                pre = c + 1 + AHEAD              # the next panel's first chunks from the last chunks on
+                self.pending_dma = self.dma_items(pre, wrap=(pre % NCH == NCH - 1))
             self.dma_first()
             if i % WAITN == 0:
                 self.e("WAITFRAG", "waitfrag", frag=tags[min(i + WAITN - 1, nfr - 1)])
             rs = self.ringpos % NRING
             self.ringpos += 1
             reg = RING + 4 * rs
-            if i == 0:
+            if part == 0 and i == 0:
                 self.e("v_mfma_f32_32x32x16_f16 %s, %s, %s, 0" % (vr(d, 16), vr(reg, 4), ar(ONESB, 4)), "mfma",
                        rd=R(reg, 4) + R(ONESB, 4, "a"), wr=R(d, 16), frag=tags[i], acc=False)
             else:
-                ks = i - 1
+                ks = 20 * part + (i - 1 if part == 0 else i)
                 self.e("v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (vr(d, 16), vr(reg, 4), ar(ZF + 4 * ks, 4), vr(d, 16)), "mfma",
                        rd=R(reg, 4) + R(ZF + 4 * ks, 4, "a") + R(d, 16), wr=R(d, 16), frag=tags[i], acc=True)
             self.mpos += 1
@@ -205,16 +214,17 @@ class Gen:
             if j < nfr:
                 self.read_frag(slot, j, rs, tags[j])
             elif not last:
-                self.read_frag((n + 1) % NSLOT, j - nfr, rs, (n + 1, j - nfr))
+                self.read_frag((c + 1) % NSLOT, j - nfr, rs, (c + 1, j - nfr))
             self.dma_second()
             self.dispense()
-        self.queue.append(("GATE", self.mpos + 3))
-        self.q_store(n)
+        if part == PARTS - 1:
+            self.queue.append(("GATE", self.mpos + 3))
+            self.q_store(n)
 
     # ---- the statement of one panel ---------------------------------------------------------------------------------------
     def build(self):
         e = self.e
-        assert NTILE % NSLOT == 0, (NTILE, NSLOT)
+        assert NCH % NSLOT == 0, (NCH, NSLOT)
         e("s_mov_b32 s%d, %%[splo]" % SP, "salu")
         e("s_mov_b32 s%d, %%[sphi]" % (SP + 1), "salu")
         e("v_and_b32_e32 %s, 0x3c003c00, %%[hmask]" % v(TMP), "valu", wr=[("v", TMP)])
@@ -229,13 +239,13 @@ class Gen:
         self.emit_dma_all()
         # the NEXT panel's token rows (this lane: 20 x 16 bytes of its row) into the statement's output registers: issued behind
         # the first MFMAs, in registers long before the statement ends (every later counted wait retires them first)
-        if "norows" not in os.environ.get("QKV_GEN_KNOB", "").split("+"):
+        if C_IN == 320 and "norows" not in os.environ.get("QKV_GEN_KNOB", "").split("+"):   # (640: 160 row registers do not fit)
             for ks in range(20):
                 self.queue.append(Ins("global_load_dwordx4 %%[r%d], %%[xrow], off offset:%d" % (ks, 32 * ks), "vmem", vm=("row", ks)))
         for j in range(NRING):
             self.read_frag(0, j, j, (0, j))
-        for n in range(NTILE):
-            self.chunk(n)
+        for c in range(NCH):
+            self.chunk(c)
         # the last tile's conversions and stores have no MFMAs left to hide behind
         self.emit_dma_all()
         self.nop(7)
@@ -248,7 +258,7 @@ class Gen:
                     self.vmlog.append(it.meta["vm"])
         self.queue = []
         self.nop(1)
-        start_vm = self.vm_after(NTILE + AHEAD - 1)          # this statement's tail = the next statement's head
+        start_vm = self.vm_after(NCH + AHEAD - 1)            # this statement's tail = the next statement's head
         for i in self.ins:
             if i.kind == "startwait":
                 i.text, i.kind = "s_waitcnt vmcnt(%d)" % start_vm, "waitvm"
@@ -319,7 +329,7 @@ class Gen:
                 elif i.kind in ("valu", "trans", "swap"):
                     last_valu_wr[r] = pos
             pos += ws(i)
-        written = set(("a", i) for i in range(ZF, ZF + 80))
+        written = set(("a", i) for i in range(ZF, ZF + 4 * NKS))
         for i in walk:
             if i.kind in ("label", "comment"):
                 continue
@@ -352,7 +362,7 @@ class Gen:
         # the token rows are retired by a counted wait: some DMA piece issued behind them is waited for
         rows = [k for k, t in enumerate(self.vmlog) if t[0] == "row"]
         if rows:
-            assert any(t[0] == "dma" and t[1] < NTILE and k > rows[-1] for k, t in enumerate(self.vmlog)), "row loads never retired"
+            assert any(t[0] == "dma" and t[1] < NCH and k > rows[-1] for k, t in enumerate(self.vmlog)), "row loads never retired"
         # every tile stored exactly once, four pieces
         st = [t for t in self.vmlog if t[0] == "st"]
         assert sorted(st) == sorted([("st", n) for n in range(NTILE) for _ in range(2)]), "stores"
@@ -384,14 +394,16 @@ def main():
     g.check()
     if "--stats" in sys.argv:
         g.stats()
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lkgd_amd", "csrc", "qkv_fused_loop.inc")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lkgd_amd", "csrc",
+                       "qkv_fused_loop.inc" if C_IN == 320 else "qkv%d_fused_loop.inc" % C_IN)
+    P = "QK" if C_IN == 320 else "QK%d" % (C_IN // 100)
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_qkv_asm.py - do not edit.  Panel statement of qkv_fused.hip (plan: see that script).\n")
-        f.write("#define QK_VB %d\n#define QK_VEND %d\n#define QK_AEND %d\n#define QK_ZF %d\n" % (VB, VEND, AEND, ZF))
-        f.write("#define QK_W1_BYTES %d\n#define QK_SLOT %d\n#define QK_NSLOT %d\n#define QK_NTILE %d\n#define QK_AHEAD %d\n" % (W1_BYTES, SLOT, NSLOT, NTILE, AHEAD))
-        f.write("#define QK_PANEL_ASM \\\n  %s\n\n" % g.text())
+        f.write("#define %s_VB %d\n#define %s_VEND %d\n#define %s_AEND %d\n#define %s_ZF %d\n#define %s_PARTS %d\n" % (P, VB, P, VEND, P, AEND, P, ZF, P, PARTS))
+        f.write("#define %s_W1_BYTES %d\n#define %s_W2_BYTES %d\n#define %s_SLOT %d\n#define %s_NSLOT %d\n#define %s_NTILE %d\n#define %s_AHEAD %d\n" % (P, W1_BYTES, P, W2_BYTES, P, SLOT, P, NSLOT, P, NTILE, P, AHEAD))
+        f.write("#define %s_PANEL_ASM \\\n  %s\n\n" % (P, g.text()))
         clob = ['"v%d"' % i for i in range(VB, VEND)] + ['"a%d"' % i for i in range(AEND)] + ['"s%d"' % i for i in range(SP, SP + 2)]
-        f.write("#define QK_CLOBBERS " + ", ".join(clob) + ', "vcc", "scc", "m0", "memory"\n')
+        f.write("#define %s_CLOBBERS " % P + ", ".join(clob) + ', "vcc", "scc", "m0", "memory"\n')
     print("wrote", out)
 
 

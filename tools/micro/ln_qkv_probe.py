@@ -9,16 +9,17 @@ from lkgd_amd import ops
 from lkgd_amd.packing import pack_ln_proj, pack_linear
 from test_ln_qkv_gpu import _weights, _ref
 T = int(os.environ.get("PROBE_T", "128"))
-w, b = _weights(1)
+C = int(os.environ.get("PROBE_C", "320"))
+w, b = _weights(1, C)
 g = torch.Generator().manual_seed(2)
-x = (torch.randn(T, 320, generator=g) * 1.5 + 0.3).half()
+x = (torch.randn(T, C, generator=g) * 1.5 + 0.3).half()
 ws = pack_ln_proj(w, b).cuda()
-out = torch.full((T, 960), float("nan"), dtype=torch.float16, device="cuda")
+out = torch.full((T, 3 * C), float("nan"), dtype=torch.float16, device="cuda")
 print("launch", flush=True)
 ops.ln_qkv(x.cuda(), ws, out)
 torch.cuda.synchronize()
 print("done", flush=True)
-if T <= 100000:
+if T <= 60000:
     ref = _ref(x, w, b)
     err = (out.float().cpu() - ref).abs()
     print("T", T, "max err", err.max().item(), "nan", torch.isnan(out).sum().item(), "ref scale", ref.abs().max().item())
@@ -35,10 +36,11 @@ else:
         e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n
     wp = pack_linear(w).cuda(); cs = wp.float().sum(dim=1).contiguous(); bd = b.cuda()
     chain = torch.empty_like(out); ln = torch.empty_like(xd)
-    def folded(): ops.gemm(xd, wp, chain, M=T, N=960, K=320, bias=bd, ln=(cs, 1e-5))
+    def folded():
+        if C == 320: ops.gemm(xd, wp, chain, M=T, N=960, K=320, bias=bd, ln=(cs, 1e-5))
     def two():
         ops.layernorm(xd, None, None, 1e-5, out=ln)
-        ops.gemm(ln, wp, chain, M=T, N=960, K=320, bias=bd)
+        ops.gemm(ln, wp, chain, M=T, N=3 * C, K=C, bias=bd)
     a0 = torch.randn(8192, 8192, device="cuda", dtype=torch.float16)
     t0 = time.time()
     while time.time() - t0 < 2.0:
