@@ -149,6 +149,13 @@ int lkgd_groupnorm_stats_cols(const float* cs0, int32_t blk0, int32_t ldcs0, int
 int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
                          int64_t nsamples, int64_t rows_per_sample, const float* stats, const float* gamma,
                          const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);
+/* the whole F.group_norm (+ F.silu) of a tensor in one call: out = silu?(groupnorm(x)); statistics pass + apply pass, the
+ * finalize step inside the apply pass's prologue where a sample has few chunk partials (two launches instead of three; the
+ * same numbers as lkgd_groupnorm_stats + lkgd_groupnorm_apply, bit for bit).  `partial` as above; `stats` (nsamples*32*2
+ * floats) is scratch the three-launch form writes (mean, rstd) to. */
+int lkgd_groupnorm_silu(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1, int64_t nsamples,
+                        int64_t rows_per_sample, float eps, float* partial, float* stats, const float* gamma,
+                        const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 3. LayerNorm over the channel dimension of a token matrix, optional row-indexed bias added BEFORE normalising
@@ -422,9 +429,12 @@ const char* lkgd_version(void);
  *    process-global variable that every later launch of the op, on any thread and stream, reads.  They exist for the
  *    A/B tools under tools/ and for the per-variant parity tests (tests/test_kernels_gpu.py); a product caller never
  *    needs them.  Value 0 (or -1 where noted) restores the automatic behaviour.
- *      lkgd_debug_set_gemm_variant(v)   force a tile program of lkgd_gemm_f16 where it applies: 1 = 128x128, 2 = 256x128 ring,
+ *      lkgd_debug_set_gemm_variant(v)   force a tile program of lkgd_gemm_f16 where it applies: 1 = 128x128, 2 = 256x128 ring, 7 = 128x128 on a four-stage ring (few-row problems),
  *                                       3 = persistent 256x128, 4 = 256x320, 5 = row-panel, 6 = resident-weight; 0 = auto
  *      lkgd_debug_set_gemm_splitk(on)   0 = never cut K into slices
+ *      lkgd_debug_set_mid_model(tk, fix, red, tbs, forced)   cost model of the four-stage 128x128 program's K slicing (us per
+ *                                       K-tile, us per workgroup, us per reduce pass, TB/s of the reduce pass; <= 0 keeps a value);
+ *                                       forced > 0 = that many slices where legal
  *      lkgd_debug_set_wide_ksplit(k)    force k K-slices on the 256x320 program where legal; 0 = rule
  *      lkgd_debug_set_wide_lds_out(on)  256x320 program: 0 = direct 8-byte stores everywhere, 1 / -1 = rows through LDS where used
  *      lkgd_debug_set_attn_waves(nw)    spatial attention: waves per workgroup (4 / 8 / 16); 0 = by sequence length
@@ -432,9 +442,12 @@ const char* lkgd_version(void);
  *      lkgd_debug_set_attn_pipe(mode)   spatial attention: 1 = never the software-pipelined program (attn_spatial_pipe.hip),
  *                                       2 = wherever it is legal (S >= 128; S % 128 != 0 runs its masked form); 0 = by sequence length
  *      lkgd_debug_set_gn_apply_kb(kb) / lkgd_debug_set_gn_stats_kb(kb)   GroupNorm chunk sizes in KiB (>= 32)
+ *      lkgd_debug_set_gn_target_wgs(n)  workgroups a GroupNorm pass aims at on small maps (chunks shrink to 8 KiB); 1 = fixed sizes
+ *      lkgd_debug_set_gn_fuse_finalize(on)   lkgd_groupnorm_silu: 0 = always the three-launch form
  * ------------------------------------------------------------------------------------------------------------- */
 void lkgd_debug_set_gemm_variant(int32_t v);
 void lkgd_debug_set_gemm_splitk(int32_t on);
+void lkgd_debug_set_mid_model(float tk_us, float fix_us, float red_us, float red_tbs, int32_t forced);
 void lkgd_debug_set_wide_ksplit(int32_t k);
 void lkgd_debug_set_wide_lds_out(int32_t on);
 void lkgd_debug_set_attn_waves(int32_t nw);
@@ -442,6 +455,8 @@ void lkgd_debug_set_attn_kvb(int32_t kvb);
 void lkgd_debug_set_attn_pipe(int32_t mode);
 void lkgd_debug_set_gn_apply_kb(int32_t kb);
 void lkgd_debug_set_gn_stats_kb(int32_t kb);
+void lkgd_debug_set_gn_target_wgs(int32_t n);
+void lkgd_debug_set_gn_fuse_finalize(int32_t on);
 
 #ifdef __cplusplus
 }

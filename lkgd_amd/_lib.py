@@ -64,6 +64,7 @@ SYMBOLS = {
     "lkgd_groupnorm_stats": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp]),
     "lkgd_groupnorm_sums": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp]),
     "lkgd_groupnorm_finalize": (_i32, [_vp, _i64, C.c_double, _f32, _vp, _vp]),
+    "lkgd_groupnorm_silu": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "lkgd_groupnorm_apply": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32,
                                     _vp]),
     "lkgd_layernorm": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
@@ -104,6 +105,7 @@ SYMBOLS = {
     # debug / measurement knobs (process-global, not thread-safe: include/lkgd_hip.h, last section)
     "lkgd_debug_set_gemm_variant": (None, [_i32]),
     "lkgd_debug_set_gemm_splitk": (None, [_i32]),
+    "lkgd_debug_set_mid_model": (None, [C.c_float, C.c_float, C.c_float, C.c_float, _i32]),
     "lkgd_debug_set_wide_ksplit": (None, [_i32]),
     "lkgd_debug_set_wide_lds_out": (None, [_i32]),
     "lkgd_debug_set_attn_waves": (None, [_i32]),
@@ -111,6 +113,8 @@ SYMBOLS = {
     "lkgd_debug_set_attn_pipe": (None, [_i32]),
     "lkgd_debug_set_gn_apply_kb": (None, [_i32]),
     "lkgd_debug_set_gn_stats_kb": (None, [_i32]),
+    "lkgd_debug_set_gn_target_wgs": (None, [_i32]),
+    "lkgd_debug_set_gn_fuse_finalize": (None, [_i32]),
 }
 
 _lib = None

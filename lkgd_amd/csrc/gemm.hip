@@ -133,6 +133,146 @@ __global__ __launch_bounds__(256, 2) void lkgd_gemm_kernel(const lkgd_gemm_desc 
   gemm_epilogue<BM, BN, 256>(p, ct, t, m0, n0, tn);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Few-row variant (round 5): the same 128x128 tile and wave layout on a FOUR-stage LDS ring (128 KiB, one workgroup per
+// CU), three K-tiles of LDS-DMA in flight behind a counted s_waitcnt vmcnt.  The two-stage kernel above waits for every
+// K-tile's loads before its MFMAs (vmcnt(0) + barrier per K-step): with a second workgroup on the CU that latency is
+// hidden, but the problems of a frame-sharded rank (576 - 9216 rows) give a CU ONE workgroup or none, and a K-step then
+// costs the whole L2 / fabric round trip - 1.3-1.8 us per K-tile measured (profiles/r05_plan_profile_base.txt: 2304 x
+// 1280 x 1280 in 36 us unsplit).  ksplit > 1 as above: blockIdx.y owns K-tiles [y*per, (y+1)*per).
+#define MID_NST 4
+#define MID_NT 512
+#define MID_LDS (MID_NST * STAGE_BYTES)   // 128 KiB (holds the 64 KiB fp32 C tile in the epilogue)
+#define MID_LOADS 4                       // LDS-DMA instructions per thread and stage (2 A + 2 B)
+
+__global__ __launch_bounds__(MID_NT, 2) void lkgd_gemm_mid_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit,
+                                                                  int per, float* ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w = t >> 6;              // 0..7: two waves per SIMD, so one wave's fragment reads and LDS-DMA issue run under
+  const int wr = w >> 1, wc = w & 1; // the other's MFMAs; wave tile 32 x 64 (4 x 2 waves)
+
+  const int nwg = tiles_m * tiles_n;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging: slot = row*8 + chunk; thread t fills A slots t + 512*i and B slots t + 512*i (i < 2): row = (t>>3) + 64*i
+  const int srow = t >> 3;
+  const int schunk = (t & 7) ^ ((t >> 4) & 7);           // logical 16-byte chunk this thread fetches (swizzled)
+  AGather<2> ag;
+  const half_t* brow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ag.row[i] = a_row(p, m0 + srow + 64 * i);
+    int n = n0 + srow + 64 * i;
+    brow[i] = n < p.N ? (const half_t*)p.w + (long long)n * p.K + schunk * 8 : nullptr;
+  }
+  const int nk_all = p.K / BK;
+  const int kb = ksplit > 1 ? (int)blockIdx.y * per : 0;
+  const int ke = ksplit > 1 ? (kb + per < nk_all ? kb + per : nk_all) : nk_all;
+  const int nkt = ke - kb;
+  a_segment<2>(p, ag, kb * BK, schunk);
+
+  auto stage = [&](int buf, int kt) {
+    char* sa = smem + buf * STAGE_BYTES;
+    char* sb = sa + BM * BK * 2;
+    const int k0 = kt * BK;
+    if (k0 >= ag.seg_end) a_segment<2>(p, ag, k0, schunk);      // wave-uniform: K-tiles are staged in order
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(a_chunk<2>(ag, i, k0), sa + (w * 64 + 512 * i) * 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      glds16(brow[i] ? brow[i] + k0 : (const half_t*)p.zeros, sb + (w * 64 + 512 * i) * 16);
+  };
+
+  float16_t acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // fragment read addresses (bytes inside a stage): row*128 + ((ks*2 + h) ^ ((row>>1)&7))*16
+  const int h = lane >> 5;
+  const int ra = wr * 32 + (lane & 31);
+  const int a_off = ra * 128, a_sw = (ra >> 1) & 7;
+  int b_off[2], b_sw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int rb = wc * 64 + j * 32 + (lane & 31);
+    b_off[j] = BM * BK * 2 + rb * 128; b_sw[j] = (rb >> 1) & 7;
+  }
+
+  for (int s = 0; s < MID_NST - 1 && s < nkt; ++s) stage(s, kb + s);
+  int cur = 0;
+  for (int i = 0; i < nkt; ++i) {
+    // tile i must have landed: this thread leaves only the (at most two) NEWER tiles' loads outstanding; the barrier then
+    // makes every thread's tile-i loads visible and frees the buffer of tile i-1 for restaging
+    const int newer = nkt - 1 - i;
+#ifndef MID_X_NOBAR        /* MID_X_*: timing experiments only (tools/micro/mid_knobs.sh), results wrong by construction */
+    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+    const char* sbase = smem + cur * STAGE_BYTES;
+    half8_t af[4], bf[4][2];                     // the whole K-tile's fragments: 12 reads in flight in front of the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#ifdef MID_X_NOLDS
+      af[ks] = (half8_t)(half_t)(float)(lane + i);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[ks][j] = (half8_t)(half_t)(float)(lane - i + j);
+#else
+      af[ks] = *(const half8_t*)(sbase + a_off + (((ks * 2 + h) ^ a_sw) << 4));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[ks][j] = *(const half8_t*)(sbase + b_off[j] + (((ks * 2 + h) ^ b_sw[j]) << 4));
+#endif
+    }
+#ifndef MID_X_NODMA
+    if (i + MID_NST - 1 < nkt) {
+      int nb = cur + MID_NST - 1; if (nb >= MID_NST) nb -= MID_NST;
+      stage(nb, kb + i + MID_NST - 1);
+    }
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#ifdef MID_X_NOMFMA
+        acc[j][ks] += (float)af[ks][j] * (float)bf[ks][j][0];
+#else
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[ks][j], acc[j], 0, 0, 0);
+#endif
+      }
+    cur = cur + 1 == MID_NST ? 0 : cur + 1;
+  }
+  __syncthreads();   // all waves done reading the ring before it becomes the C tile
+
+  float* ct = (float*)smem;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      int col = wc * 64 + j * 32 + (lane & 31);
+      ct[row * BN + col] = acc[j][r];
+    }
+  __syncthreads();
+
+  if (ksplit > 1) {
+    float* dst = ws + (long long)blockIdx.y * p.M * p.N;
+    const int col = (t & 31) * 4;
+    if (n0 + col < p.N) {
+      for (int row = t >> 5; row < BM && m0 + row < p.M; row += 16)
+        *(float4_t*)(dst + (long long)(m0 + row) * p.N + n0 + col) = *(const float4_t*)(ct + row * BN + col);
+    }
+    return;
+  }
+  gemm_epilogue<BM, BN, MID_NT>(p, ct, t, m0, n0, tn);
+}
+
 // second pass of a split-K GEMM: 32 x 128 output tile per workgroup, partials added in slice order, then the shared epilogue
 __global__ __launch_bounds__(256) void lkgd_gemm_splitk_reduce(const lkgd_gemm_desc p, int tiles_n, int ksplit,
                                                                const float* ws) {
@@ -330,7 +470,7 @@ extern "C" int lkgd_gemm_resw_colstats_ok(const lkgd_gemm_desc* d);
 // 5 = force the register-resident row-panel kernel where it applies (plain A, K <= 320),
 // 6 = force the resident-weight kernel where it applies (plain A, K <= 320, N % 160 == 0)
 static int gemm_variant_override = 0;
-extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 6) ? v : 0; }
+extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 7) ? v : 0; }   // 7 = 128x128 on the four-stage ring
 extern "C" void lkgd_debug_set_gemm_splitk(int on);
 
 // Split-K for the 256x320 kernel on problems whose tiles leave CUs idle (fewer tiles than CUs): EQUAL K slices (a divisor
@@ -370,6 +510,36 @@ static int wide_split(const lkgd_gemm_desc* d, long long tiles_wide, int cus) {
 
 extern "C" void lkgd_debug_set_gemm_splitk(int on) { gemm_splitk_enabled = on != 0; }
 
+// K slices of the four-stage 128x128 kernel (one workgroup per CU): the slice count with the smallest MODELLED time.  A
+// workgroup costs a fixed part (prologue, pipeline fill, epilogue or partial-tile store) plus its K-tiles; slicing adds the
+// reduce pass, which reads ks fp32 copies of the output.  Constants from tools/micro/mid_knobs.py (time over K at 2304 x 1280:
+// 0.75 us per K-tile, 5-6 us fixed; profiles/r05_gemm_mid_knobs.txt); 1 = unsplit.
+static float mid_tk_us = 0.75f, mid_fix_us = 6.0f, mid_red_us = 5.0f, mid_red_tbs = 3.5f;
+static int mid_ksplit_forced = 0;
+extern "C" void lkgd_debug_set_mid_model(float tk, float fix, float red, float tbs, int forced) {
+  if (tk > 0) mid_tk_us = tk;
+  if (fix > 0) mid_fix_us = fix;
+  if (red > 0) mid_red_us = red;
+  if (tbs > 0) mid_red_tbs = tbs;
+  mid_ksplit_forced = forced < 0 ? 0 : forced;
+}
+static int mid_split(const lkgd_gemm_desc* d, long long nwg, int nk, int cus) {
+  if (!d->workspace || !aligned16(d->workspace) || d->N % 4) return 1;
+  const long long fit = d->workspace_bytes / ((long long)d->M * d->N * 4);
+  if (mid_ksplit_forced) return (mid_ksplit_forced <= nk && mid_ksplit_forced <= fit) ? mid_ksplit_forced : 1;
+  if (!gemm_splitk_enabled || nk < 16) return 1;
+  int best = 1;
+  float best_t = 1e30f;
+  for (int ks = 1; ks <= 16 && ks <= fit && ks * 8 <= nk; ++ks) {
+    const int per = (nk + ks - 1) / ks;
+    const long long blocks = nwg * ((nk + per - 1) / per), rounds = (blocks + cus - 1) / cus;
+    float t = (float)rounds * (mid_fix_us + per * mid_tk_us);
+    if (ks > 1) t += mid_red_us + (float)ks * (float)d->M * (float)d->N * 4.0f / (mid_red_tbs * 1e6f);
+    if (t < best_t * 0.97f) { best_t = t; best = ks; }      // more slices only for a clear gain
+  }
+  return best;
+}
+
 static int gemm_cus(int* cus_out) {
   static std::atomic<int> cus_of[64];
   int dev = 0;
@@ -387,7 +557,7 @@ static int gemm_cus(int* cus_out) {
 
 // tile-program choice for a checked descriptor: 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide (256x320), 5 = row-panel,
 // 6 = resident-weight; *wide_ks_out = K slices of the 256x320 program (1 = none); negative = LKGD_E_*
-static int gemm_pick(const lkgd_gemm_desc* d, int cus, int* wide_ks_out) {
+static int gemm_pick(const lkgd_gemm_desc* d, int cus, int* wide_ks_out) {   // (7 = 128x128 on the four-stage ring)
   // GEGLU weights are packed for one tile family (interleave width 80 -> 256x320 tiles, 32 -> 128-wide tiles)
   // the persistent kernels move epilogue rows as 16-byte chunks: 8-channel granularity and 16-byte aligned rows
   const bool rows16 = d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->out) &&
@@ -445,6 +615,10 @@ static int gemm_pick(const lkgd_gemm_desc* d, int cus, int* wide_ks_out) {
     // the 9x16 level (M = 4032; also the 9216-row 36x64 level of a rank of 8): 256-row tilings leave most CUs idle; 128x128
     // at two workgroups per CU fills best, except for the wide-N projections (QKV: 16 x 12 tiles of 256x320)
     pick = (wide_ok && plain && d->geglu == 0 && d->N % 320 == 0 && d->N >= 2560 && d->M >= 2048 && !d->res1) ? 4 : 1;
+    // 128x128 tiles that give a CU one workgroup at most (the 18x32 / 9x16 levels of a frame-sharded rank, the full model's
+    // 9x16 level): the four-stage ring instead of the two-stage kernel, whose K-steps then wait out every load - 2304 x 1280 x
+    // 1280 0.022 vs 0.036 ms, the 576-row temporal conv 0.025 vs 0.033, ff-out 0.029 vs 0.036 (profiles/r05_gemm_mid_ab.txt)
+    if (pick == 1 && d->geglu == 0 && (long long)((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN) <= cus) pick = 7;
   } else {
     pick = 3;
   }
@@ -492,7 +666,9 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
     if (hipFuncSetAttribute((const void*)lkgd_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) !=
             hipSuccess ||
         hipFuncSetAttribute((const void*)lkgd_gemm_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GEMM2_LDS) != hipSuccess)
+                            GEMM2_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lkgd_gemm_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS) !=
+            hipSuccess)
       return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
   int cus = 0;
@@ -515,6 +691,26 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   }
   if (pick == 3) return lkgd_gemm_stream_launch(d, (hipStream_t)stream, cus);
   int tiles_n = (d->N + BN - 1) / BN;
+  if (pick == 7) {
+    const int tiles_m = (d->M + BM - 1) / BM;
+    const long long nwg = (long long)tiles_m * tiles_n;
+    if (nwg > 0x7fffffffLL) return LKGD_E_SHAPE;
+    const int nk = d->K / BK;
+    const int ksplit = mid_split(d, nwg, nk, cus);
+    if (ksplit > 1) {
+      const int per = (nk + ksplit - 1) / ksplit;
+      const int ks = (nk + per - 1) / per;           // every slice non-empty
+      hipLaunchKernelGGL(lkgd_gemm_mid_kernel, dim3((unsigned)nwg, (unsigned)ks), dim3(MID_NT), MID_LDS, (hipStream_t)stream, *d,
+                         tiles_m, tiles_n, ks, per, (float*)d->workspace);
+      const unsigned rblocks = (unsigned)(((d->M + 31) / 32) * tiles_n);
+      hipLaunchKernelGGL(lkgd_gemm_splitk_reduce, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *d, tiles_n, ks,
+                         (const float*)d->workspace);
+    } else {
+      hipLaunchKernelGGL(lkgd_gemm_mid_kernel, dim3((unsigned)nwg), dim3(MID_NT), MID_LDS, (hipStream_t)stream, *d, tiles_m,
+                         tiles_n, 1, nk, (float*)nullptr);
+    }
+    return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+  }
   // deep-K problems (3x3 / temporal convs, K >= 960) take the 256x128 three-stage ring: its two K-tiles in flight hide
   // the HBM latency the two-stage kernel exposes every K-step.  Short-K GEMMs (K = 320/640 projections at 258k rows) are
   // epilogue-bound; they keep 128x128 tiles at two workgroups per CU so one workgroup's epilogue overlaps the other's

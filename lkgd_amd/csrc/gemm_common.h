@@ -332,37 +332,55 @@ __device__ __forceinline__ void gemm_epilogue(const lkgd_gemm_desc& p, const flo
     if (gcol < p.N) {
       float4_t bias = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bias = *(const float4_t*)(p.bias + gcol);
-#pragma unroll 4
-      for (int it = 0; it < BM_ / RPP; ++it) {
-        int row = (t / TPR) + RPP * it;
-        long long m = m0 + row;
-        if (m >= p.M) break;
-        float4_t v = *(const float4_t*)(ct + row * BN_ + col);
-        v += bias;
-        if (rbp) {
-          // M is an int32: 32-bit unsigned row-map arithmetic (a 64-bit division is a few hundred instructions)
-          const unsigned mu = (unsigned)m;
-          const unsigned idx = ((mu / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (mu % (unsigned)p.rb_d2) +
-                                (unsigned)p.rb_c0) % (unsigned)p.rb_md;
-          half4_t rb = *(const half4_t*)(rbp + (long long)idx * p.ldrb + gcol);
+      // rows in batches of EB: a batch's residual / row-bias loads are all issued before its arithmetic (one exposed memory
+      // round trip per batch instead of one per row - with one workgroup on a CU nothing else covers them)
+      constexpr int NIT = BM_ / RPP;
+      constexpr int EB = NIT < 8 ? NIT : 8;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
+      for (int it0 = 0; it0 < NIT; it0 += EB) {
+        half4_t rbv[EB], r1v[EB], r2v[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+          const half4_t z = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+          rbv[u] = z; r1v[u] = z; r2v[u] = z;
+          const long long m = m0 + (t / TPR) + RPP * (it0 + u);
+          if (m < p.M) {
+            if (rbp) {
+              // M is an int32: 32-bit unsigned row-map arithmetic (a 64-bit division is a few hundred instructions)
+              const unsigned mu = (unsigned)m;
+              const unsigned idx = ((mu / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (mu % (unsigned)p.rb_d2) +
+                                    (unsigned)p.rb_c0) % (unsigned)p.rb_md;
+              rbv[u] = *(const half4_t*)(rbp + (long long)idx * p.ldrb + gcol);
+            }
+            if (r1p) r1v[u] = *(const half4_t*)(r1p + m * p.ldr1 + gcol);
+            if (r2p) r2v[u] = *(const half4_t*)(r2p + m * p.ldr2 + gcol);
+          }
         }
-        v *= p.s_acc;
-        if (r1p) {
-          half4_t r = *(const half4_t*)(r1p + m * p.ldr1 + gcol);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += p.r1 * (float)r[e];
+        for (int u = 0; u < EB; ++u) {
+          const int row = (t / TPR) + RPP * (it0 + u);
+          const long long m = m0 + row;
+          if (m >= p.M) break;
+          float4_t v = *(const float4_t*)(ct + row * BN_ + col);
+          v += bias;
+          if (rbp) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rbv[u][e];
+          }
+          v *= p.s_acc;
+          if (r1p) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += p.r1 * (float)r1v[u][e];
+          }
+          if (r2p) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += p.r2 * (float)r2v[u][e];
+          }
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+          *(half4_t*)(outp + m * p.ldc + gcol) = o;
         }
-        if (r2p) {
-          half4_t r = *(const half4_t*)(r2p + m * p.ldr2 + gcol);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += p.r2 * (float)r[e];
-        }
-        half4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-        *(half4_t*)(outp + m * p.ldc + gcol) = o;
       }
     }
   } else {

@@ -2,21 +2,32 @@
 // HBM-bound kernels: 16-byte loads/stores, fp32 statistics, deterministic reductions (no float atomics to HBM).
 #include "common.h"
 
-// rows of one sample handled by one workgroup: ~32 KiB of activations per workgroup, so that small feature maps still
-// spread over all 256 CUs (18x32 @ 1280 channels: 12 rows -> 1344 workgroups instead of 252)
+// rows of one sample handled by one workgroup.  Large maps: ~32 KiB of activations per apply workgroup, 128 KiB per
+// statistics workgroup (fewer, larger partial sums; measured best at the 72x128 level).  Small maps - the 18x32 / 9x16
+// levels, every level of a frame-sharded rank - are cut finer, down to 8 KiB, so that a launch still has about GN_TARGET_WGS
+// workgroups: with 128-KiB chunks the 18x32 map of a rank of 8 (5.9 MB) was 48 workgroups walking 512 bytes per thread one
+// 8-load batch after the other (8-10 us per launch, profiles/r05_plan_profile_base.txt).
 static int gn_apply_kb = 32;
 extern "C" void lkgd_debug_set_gn_apply_kb(int kb) { gn_apply_kb = kb < 32 ? 32 : kb; }
-static inline int gn_rows(int C) {
-  int r = gn_apply_kb * 1024 / (C * 2);
-  return r < 8 ? 8 : (r > 1024 ? 1024 : r);
-}
-// the statistics pass may use longer chunks than the apply pass (fewer, larger workgroups; the partial buffer is sized for
-// the apply pass's chunk count, which is never smaller)
 static int gn_stats_kb = 128;
 extern "C" void lkgd_debug_set_gn_stats_kb(int kb) { gn_stats_kb = kb < 32 ? 32 : kb; }
-static inline int gn_rows_stats(int C) {
-  int r = gn_stats_kb * 1024 / (C * 2);
-  return r < 8 ? 8 : (r > 1024 ? 1024 : r);
+static int gn_target_wgs = 1024;
+extern "C" void lkgd_debug_set_gn_target_wgs(int n) { gn_target_wgs = n < 1 ? 1 : n; }   // 1 = the fixed chunk sizes only
+static inline int gn_rows_kb(int C, int kb, long long rows_per_sample, long long nsamples) {
+  int rmax = kb * 1024 / (C * 2);
+  rmax = rmax < 8 ? 8 : (rmax > 1024 ? 1024 : rmax);
+  int rmin = 8 * 1024 / (C * 2);
+  rmin = rmin < 8 ? 8 : rmin;
+  if (rmin > rmax) rmin = rmax;
+  const long long want = (rows_per_sample * nsamples + gn_target_wgs - 1) / gn_target_wgs;   // rows per chunk for ~target chunks
+  return (int)(want < rmin ? rmin : (want > rmax ? rmax : want));
+}
+static inline int gn_rows(int C, long long rows_per_sample, long long nsamples) {
+  return gn_rows_kb(C, gn_apply_kb, rows_per_sample, nsamples);
+}
+// the statistics pass may use longer chunks than the apply pass (the partial buffer is sized by lkgd_groupnorm_chunks)
+static inline int gn_rows_stats(int C, long long rows_per_sample, long long nsamples) {
+  return gn_rows_kb(C, gn_stats_kb, rows_per_sample, nsamples);
 }
 #define GN_GROUPS 32
 #define GN_MAXC 4096
@@ -192,10 +203,16 @@ __global__ void gn_finalize_sums_kernel(const float* sums, long long n, double i
   stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// FIN: the (mean, rstd) of the sample's 32 groups are reduced from the statistics pass's chunk partials in the prologue -
+// the arithmetic of gn_finalize_kernel (one wave per group, the same lane -> chunk map and butterfly: bitwise the same
+// numbers) - instead of being read from `stats`: one launch less per GroupNorm where a sample has few chunks.
+template <bool FIN>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0, int ld0, const half_t* x1, int c1,
                                                        int ld1, long long rows_per_sample, const float* stats,
                                                        const float* gamma, const float* beta, int silu,
-                                                       half_t* out, int ldo, int GN_ROWS) {
+                                                       half_t* out, int ldo, int GN_ROWS, const float* partial,
+                                                       int nchunks_stats, double inv_count, float eps) {
+  __shared__ float s_stats[GN_GROUPS * 2];
   const int C = c0 + c1;
   const GnMap mp = gn_map(C);
   const int t = threadIdx.x;
@@ -205,6 +222,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0,
   if (r1 > rows_per_sample) r1 = rows_per_sample;
   const long long base = sample * rows_per_sample;
   const int gs = C / GN_GROUPS;
+  if (FIN) {
+    const int lane = t & 63, wv = t >> 6;
+    for (int g = wv; g < GN_GROUPS; g += 4) {
+      double sa, sb;
+      gn_reduce_pair(partial, nchunks_stats, sample, g, lane, sa, sb);
+      if (lane == 0) {
+        double mean = sa * inv_count;
+        double var = sb * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_stats[g * 2 + 0] = (float)mean;
+        s_stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+      }
+    }
+    __syncthreads();
+  }
   for (int slot = 0; slot < mp.nslot; ++slot) {
     int cv, rp;
     if (mp.nslot == 1) { rp = t / mp.C8; cv = t - rp * mp.C8; if (rp >= mp.rows_par) continue; }
@@ -218,7 +250,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0,
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int g = (cv * 8 + e) / gs;
-        const float2_t mr = *(const float2_t*)(stats + (sample * GN_GROUPS + g) * 2);
+        float2_t mr;
+        if (FIN) { mr[0] = s_stats[g * 2]; mr[1] = s_stats[g * 2 + 1]; }
+        else mr = *(const float2_t*)(stats + (sample * GN_GROUPS + g) * 2);
         const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
         A[e] = mr[1] * ga;
         B[e] = be - mr[0] * A[e];
@@ -252,7 +286,8 @@ static int gn_check(const void* x0, int c0, int ld0, const void* x1, int c1, int
 }
 
 extern "C" int lkgd_groupnorm_chunks(int64_t rows_per_sample, int32_t C) {   // sizes the caller's `partial` scratch
-  const int ra = gn_rows(C), rs = gn_rows_stats(C);
+  // chunk rows never shrink with the sample count: one sample gives the largest chunk count
+  const int ra = gn_rows(C, rows_per_sample, 1), rs = gn_rows_stats(C, rows_per_sample, 1);
   const int r = ra < rs ? ra : rs;
   return (int)((rows_per_sample + r - 1) / r);
 }
@@ -263,7 +298,7 @@ extern "C" int lkgd_groupnorm_stats(const void* x0, int32_t c0, int32_t ld0, con
   int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
   if (rc) return rc;
   if (!partial || !stats) return LKGD_E_NULL;
-  const int rs = gn_rows_stats(c0 + c1);
+  const int rs = gn_rows_stats(c0 + c1, rows_per_sample, nsamples);
   int nchunks = (int)((rows_per_sample + rs - 1) / rs);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
@@ -296,7 +331,7 @@ extern "C" int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, cons
   int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
   if (rc) return rc;
   if (!partial || !sums) return LKGD_E_NULL;
-  const int rs = gn_rows_stats(c0 + c1);
+  const int rs = gn_rows_stats(c0 + c1, rows_per_sample, nsamples);
   int nchunks = (int)((rows_per_sample + rs - 1) / rs);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
@@ -324,11 +359,48 @@ extern "C" int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, con
   if (rc) return rc;
   if (!stats || !gamma || !beta || !out) return LKGD_E_NULL;
   if (ldo % 8 || !aligned16(out)) return LKGD_E_ALIGN;
-  const int ra = gn_rows(c0 + c1);
+  const int ra = gn_rows(c0 + c1, rows_per_sample, nsamples);
   int nchunks = (int)((rows_per_sample + ra - 1) / ra);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, stats, gamma,
-                     beta, silu, (half_t*)out, ldo, gn_rows(c0 + c1));
+                     beta, silu, (half_t*)out, ldo, ra, (const float*)nullptr, 0, 0.0, 0.f);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
+// The whole GroupNorm (+ SiLU) of a tensor in one call: statistics pass, then the apply pass with the finalize step in its
+// prologue where a sample has at most GN_FIN_MAX_CHUNKS chunk partials (two launches), else statistics + finalize + apply.
+#define GN_FIN_MAX_CHUNKS 256
+static int gn_fuse_finalize = 1;
+extern "C" void lkgd_debug_set_gn_fuse_finalize(int on) { gn_fuse_finalize = on != 0; }
+extern "C" int lkgd_groupnorm_silu(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
+                                   int64_t nsamples, int64_t rows_per_sample, float eps, float* partial, float* stats,
+                                   const float* gamma, const float* beta, int32_t silu, void* out, int32_t ldo,
+                                   lkgd_stream_t stream) {
+  int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
+  if (rc) return rc;
+  if (!partial || !stats || !gamma || !beta || !out) return LKGD_E_NULL;
+  if (ldo % 8 || !aligned16(out)) return LKGD_E_ALIGN;
+  const int C = c0 + c1;
+  const int rs = gn_rows_stats(C, rows_per_sample, nsamples);
+  const int nchunks = (int)((rows_per_sample + rs - 1) / rs);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
+                     nchunks, rs);
+  const double inv = 1.0 / ((double)rows_per_sample * (double)(C / GN_GROUPS));
+  const int ra = gn_rows(C, rows_per_sample, nsamples);
+  const int achunks = (int)((rows_per_sample + ra - 1) / ra);
+  if (gn_fuse_finalize && nchunks <= GN_FIN_MAX_CHUNKS) {
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(achunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample,
+                       (const float*)nullptr, gamma, beta, silu, (half_t*)out, ldo, ra, (const float*)partial, nchunks, inv,
+                       eps);
+  } else {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
+                       nchunks, inv, eps, stats);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(achunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample,
+                       (const float*)stats, gamma, beta, silu, (half_t*)out, ldo, ra, (const float*)nullptr, 0, 0.0, 0.f);
+  }
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 

@@ -252,8 +252,20 @@ def groupnorm_silu(x0, x1, nsamples, rows_per_sample, gamma, beta, eps, silu=Tru
     C_ = x0.shape[1] + (x1.shape[1] if x1 is not None else 0)
     if out is None:
         out = torch.empty(x0.shape[0], C_, dtype=torch.float16, device=x0.device)
-    stats = groupnorm_stats(x0, x1, nsamples, rows_per_sample, eps)
-    return groupnorm_apply(x0, x1, nsamples, rows_per_sample, stats, gamma, beta, silu, out)
+    _req(x0, torch.float16, "x0"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    stats = _stats_from_cols(x0, x1, nsamples, rows_per_sample, eps, False)
+    if stats is not None:            # the producing GEMMs left column sums: no read pass
+        return groupnorm_apply(x0, x1, nsamples, rows_per_sample, stats, gamma, beta, silu, out)
+    c0 = x0.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    L = _L()
+    nchunks = L.lkgd_groupnorm_chunks(rows_per_sample, c0 + c1)
+    partial = torch.empty(nsamples * nchunks * 64, dtype=torch.float32, device=x0.device)
+    stats = torch.empty(nsamples, 32, 2, dtype=torch.float32, device=x0.device)
+    check(L.lkgd_groupnorm_silu(x0.data_ptr(), c0, _ld(x0), _ptr(x1), c1, _ld(x1) if x1 is not None else 0, nsamples,
+                                rows_per_sample, eps, partial.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                1 if silu else 0, out.data_ptr(), _ld(out), _stream()), "lkgd_groupnorm_silu")
+    return out
 
 
 def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,

@@ -13,6 +13,17 @@ FULLRES_GEOM = dict(B=2, F=2, H=72, W=128)
 FULLRES_F14_SEED = 171    # inputs of the ONE-forward fixture at the headline geometry itself: CFG 2 x 14 frames x 72 x 128 (round 4)
 
 
+HEADLINE_SEED = 181       # inputs of the 25-step loop fixture at the headline geometry: 1 clip x 14 frames x 576 x 1024 px (round 5)
+
+
+def headline_inputs():
+    """(image [1,3,576,1024] in [0,1], initial latents [1,14,4,72,128] rounded to fp16) of `loop25_headline.safetensors`"""
+    g = torch.Generator().manual_seed(HEADLINE_SEED)
+    image = torch.rand(1, 3, 576, 1024, generator=g)
+    lat0 = torch.randn(1, 14, 4, 72, 128, generator=g).half().float()
+    return image, lat0
+
+
 def fullres_inputs(seed=FULLRES_SEED + 1, lk=False, frames=None):
     g = torch.Generator().manual_seed(seed)
     B, F, H, W = (FULLRES_GEOM[k] for k in "BFHW")

@@ -931,6 +931,63 @@ def gen_loop_f14(pipe_mod, ref_stock, sched_mod, guidance: bool):
     print("loop f14 (%s): final std %.4f" % ("cfg" if guidance else "no cfg", out["final"].std()))
 
 
+def gen_loop25_headline(pipe_mod, ref_stock, sched_mod):
+    """round 5: the reference `__call__` (pipeline_stable_video_diffusion_trans.py:544-640) through ALL 25 Euler steps at the
+    geometry of BASELINE.json configs[1] itself - one clip x 14 frames x 576 x 1024 px (latent 72 x 128), CFG 1 -> 3, real-width
+    UNet (weights of the other real-width fixtures) - in fp32 on the CPU: 25 x 89.7 TFLOP, about two hours here.  Stored: the
+    latents after steps 5 / 10 / 15 / 20 / 25 and the returned latents in fp16 (their rounding, 5e-4 relative, is far inside the
+    5e-2 gate), fp64 sum / abs-sum / std of EVERY step's fp32 latents, and the loop's boundary inputs.  Progress is written to
+    /tmp after every step so that a killed run leaves its partial curve behind."""
+    from fullres_cases import HEADLINE_SEED, headline_inputs
+    from oracle.unet import SVD_CONFIG
+    with torch.no_grad():
+        unet = ref_stock.UNetSpatioTemporalConditionControlNetModel(**SVD_CONFIG.__dict__)
+        ou.init_weights_(unet, C1_SEED)
+        for p in unet.parameters():
+            p.copy_(p.half().float())
+    image, lat0 = headline_inputs()
+    from oracle.scheduler import SchedulerConfig
+    sched = sched_mod.EulerDiscreteScheduler(**SchedulerConfig().__dict__)
+    fe = lambda images, **k: SimpleNamespace(pixel_values=images)   # noqa: E731
+    pipe = pipe_mod.StableVideoDiffusionPipeline(vae=_FakeVAE(), image_encoder=_FakeCLIP(), unet=unet, scheduler=sched,
+                                                 feature_extractor=fe)
+    rec, kept, stats = {}, {}, []
+    orig_forward = unet.forward
+    import time
+    t00 = time.time()
+
+    def spy(sample, t, **k):
+        if "enc" not in rec:
+            rec["enc"], rec["ids"] = k["encoder_hidden_states"].clone(), k["added_time_ids"].clone()
+            il = sample[:, :, 4:]
+            assert bool((il == il[:, :1]).all()), "image latents differ between frames"
+            rec["image_latents"] = il[:, 0].clone()
+        return orig_forward(sample, t, **k)
+
+    def on_step(p_, i, t, kw_):
+        lat = kw_["latents"]
+        d = lat.double()
+        stats.append([float(d.sum()), float(d.abs().sum()), float(d.std())])
+        if (i + 1) % 5 == 0:
+            kept[i] = lat.half().clone()
+        print("  step %d done at %.0f s, latents std %.4f" % (i, time.time() - t00, stats[-1][2]), flush=True)
+        torch.save({"stats": stats, "kept": kept}, "/tmp/loop25_headline_progress.pt")
+        return {}
+    unet.forward = spy
+    res = pipe(image, height=576, width=1024, num_frames=14, num_inference_steps=25, latents=lat0.clone(),
+               min_guidance_scale=1.0, max_guidance_scale=3.0, output_type="latent",
+               generator=torch.Generator().manual_seed(HEADLINE_SEED + 1), callback_on_step_end=on_step)
+    assert sorted(kept) == [4, 9, 14, 19, 24]
+    out = {"final_f16": res.frames.half(), "kept_steps": torch.tensor(sorted(kept)),
+           "step_latents_f16": torch.stack([kept[i] for i in sorted(kept)]),
+           "step_stats": torch.tensor(stats, dtype=torch.float64),            # [25, 3]: sum, abs-sum, std of the fp32 latents
+           "image_embeddings": rec["enc"], "added_time_ids": rec["ids"], "image_latents": rec["image_latents"].contiguous(),
+           "checksum": torch.tensor(checksum(unet), dtype=torch.float64),
+           "latents0_sum": lat0.double().sum().reshape(1)}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "loop25_headline.safetensors"))
+    print("loop25 headline: final std %.4f, %.0f s" % (res.frames.std(), time.time() - t00))
+
+
 def gen_unet_fullres(ref_stock):
     """ONE forward of the reference's stock UNet (unet_spatio_temporal_condition_controlnet.py:358-508) at the REAL width
     and the FULL latent resolution of configs[1] (72 x 128, S = 9216) with CFG 2 x 2 frames, fp32 on the CPU"""
@@ -1017,13 +1074,15 @@ def main():
         _mod("patch")
         load_ref("patch/utils.py", "patch.utils")
         return gen_patch_lora(load_ref("patch/patch.py", "patch.patch"), ref_stock)
-    if only in ("loop_f14_cfg", "loop_f14_nocfg"):                              # round-3 fixtures
+    if only in ("loop_f14_cfg", "loop_f14_nocfg", "loop25_headline"):           # round-3 / round-5 fixtures
         for m in ("models", "utils"):
             _mod(m)
         sched_mod = load_ref("utils/scheduling_euler_discrete_karras_fix.py", "utils.scheduling_euler_discrete_karras_fix")
         ref_stock = load_ref("models/unet_spatio_temporal_condition_controlnet.py",
                              "models.unet_spatio_temporal_condition_controlnet")
         pipe_mod = load_ref("pipeline/pipeline_stable_video_diffusion_trans.py", "ref_pipeline_trans")
+        if only == "loop25_headline":
+            return gen_loop25_headline(pipe_mod, ref_stock, sched_mod)
         return gen_loop_f14(pipe_mod, ref_stock, sched_mod, only == "loop_f14_cfg")
     if only in ("loop25", "loop25_c1", "unet_fullres", "unet_fullres_lk", "unet_fullres_f14"):     # one at a time
         for m in ("models", "utils"):

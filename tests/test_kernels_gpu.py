@@ -24,13 +24,13 @@ def _close(got, ref, rtol=4e-3, what=""):
     assert rel < 3e-3, f"{what}: relative L2 {rel:.4g}"
 
 
-@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel", "resw"])
+@pytest.fixture(scope="module", params=["tile128", "tile256", "stream", "wide", "rowpanel", "resw", "mid"])
 def ops(request):
     """every GEMM/conv test runs against ALL kernel variants (128x128 two-stage, 256x128 three-stage ring, persistent
-    streaming kernel with register epilogue, 256x320, row-panel, resident-weight; a forced variant falls back to the 128x128
+    streaming kernel with register epilogue, 256x320, row-panel, resident-weight, 128x128 on the four-stage ring; a forced variant falls back to the 128x128
     program on shapes it does not cover)"""
     from lkgd_amd import _lib, ops
-    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5, "resw": 6}[request.param])
+    _lib.lib().lkgd_debug_set_gemm_variant({"tile128": 1, "tile256": 2, "stream": 3, "wide": 4, "rowpanel": 5, "resw": 6, "mid": 7}[request.param])
     yield ops
     _lib.lib().lkgd_debug_set_gemm_variant(0)
 
@@ -265,6 +265,33 @@ def test_groupnorm_silu(ops, C0, C1, rows, ns):
     _close(out, ref, what="groupnorm+silu")
 
 
+@pytest.mark.parametrize("C0,C1,rows,ns", [(320, 0, 9216, 4), (1280, 0, 576, 4), (1280, 1280, 144, 4), (640, 0, 4 * 2304, 1),
+                                           (320, 0, 14 * 9216, 2), (128, 192, 77, 2)])
+def test_groupnorm_one_call_equals_three_launches_bitwise(C0, C1, rows, ns):
+    """lkgd_groupnorm_silu (statistics pass + apply pass with the finalize step in its prologue where a sample has few chunk
+    partials) against lkgd_groupnorm_stats + lkgd_groupnorm_apply on the maps of a frame-sharded rank and of the full
+    forward: the same bits, and both within tolerance of F.group_norm"""
+    from lkgd_amd import _lib, ops
+    g = torch.Generator().manual_seed(C0 + C1 + rows)
+    C = C0 + C1
+    x = _h(torch.randn(ns * rows, C, generator=g) * 2 + 0.5)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    xd = x.to(DEV)
+    x0, x1 = (xd[:, :C0], xd[:, C0:]) if C1 else (xd, None)
+    one = ops.groupnorm_silu(x0, x1, ns, rows, gamma, beta, 1e-5)
+    stats = ops.groupnorm_stats(x0, x1, ns, rows, 1e-5)
+    three = ops.groupnorm_apply(x0, x1, ns, rows, stats, gamma, beta, True, torch.empty_like(one))
+    assert torch.equal(one, three)
+    _lib.lib().lkgd_debug_set_gn_fuse_finalize(0)
+    try:
+        assert torch.equal(ops.groupnorm_silu(x0, x1, ns, rows, gamma, beta, 1e-5), one)
+    finally:
+        _lib.lib().lkgd_debug_set_gn_fuse_finalize(1)
+    sub = slice(0, min(ns * rows, 20000))
+    ref = F.silu(F.group_norm(x.float().reshape(ns, rows, C).permute(0, 2, 1), 32, gamma.cpu(), beta.cpu(), 1e-5))
+    _close(one[sub], ref.permute(0, 2, 1).reshape(ns * rows, C)[sub], what="one-call groupnorm")
+
+
 def test_layernorm_with_rowbias(ops):
     g = torch.Generator().manual_seed(20)
     for C in (64, 320, 640, 1280):
@@ -495,6 +522,36 @@ def test_gemm_split_k_few_rows():
     out = torch.empty(M, 256, dtype=torch.float16, device=DEV)
     ops.gemm(a.to(DEV), wp.to(DEV), out, M=M, N=512, K=C, bias=bp.to(DEV), geglu=half)
     _close(out, hid * F.gelu(gate), what="split-K geglu")
+
+
+def test_gemm_four_stage_ring_k_slices():
+    """the 128x128 program on the four-stage ring (few-row problems, round 5) over forced K slices: slices that do not divide
+    K evenly, a slice shorter than the ring, ragged rows; against fp32 and against its own unsplit run, bitwise repeatable"""
+    from lkgd_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(77)
+    L.lkgd_debug_set_gemm_variant(7)
+    try:
+        for M, N, K, forced in ((576, 1280, 1280, 3), (301, 320, 704, 5), (2304, 640, 1920, 2), (130, 128, 64 * 11, 4)):
+            a = _h(torch.randn(M, K, generator=g))
+            w = _h(torch.randn(N, K, generator=g) / K ** 0.5)
+            b = torch.randn(N, generator=g)
+            res = _h(torch.randn(M, N, generator=g))
+            ref = a.float() @ w.float().T + b + 0.5 * res.float()
+            outs = []
+            for f in (forced, 0, forced):
+                L.lkgd_debug_set_mid_model(0.0, 0.0, 0.0, 0.0, f)
+                L.lkgd_debug_set_gemm_splitk(1 if f else 0)
+                out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+                ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, bias=b.to(DEV), res1=res.to(DEV), r1=0.5)
+                outs.append(out.cpu())
+            _close(outs[0], ref, what=f"four-stage ring, {forced} K slices, {M}x{N}x{K}")
+            _close(outs[1], ref, what=f"four-stage ring, unsplit, {M}x{N}x{K}")
+            assert torch.equal(outs[0], outs[2])
+    finally:
+        L.lkgd_debug_set_mid_model(0.0, 0.0, 0.0, 0.0, 0)
+        L.lkgd_debug_set_gemm_splitk(1)
+        L.lkgd_debug_set_gemm_variant(0)
 
 
 def test_gemm_split_k_on_256x320_tiles():

@@ -144,8 +144,8 @@ def main_ldsout():
 
 def main_ab():
     warm()
-    variants = [0, 1, 3, 4, 5, 6]
-    names = {0: "auto", 1: "t128", 2: "t256", 3: "strm", 4: "wide", 5: "rowp", 6: "resw"}
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,3,4,5,6,7").split(",")]
+    names = {0: "auto", 1: "t128", 2: "t256", 3: "strm", 4: "wide", 5: "rowp", 6: "resw", 7: "mid"}
     print(f"{'shape':34s} {'cnt':>4s} " + " ".join(f"{names[v]:>8s}" for v in variants) + "   (ms per launch; * = best)")
     tot = {v: 0.0 for v in variants}
     tot_best = tot_f = 0.0
