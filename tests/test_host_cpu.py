@@ -31,7 +31,9 @@ def test_gemm_desc_validation_without_gpu():
     from lkgd_amd import _lib
     d = _lib.GemmDesc()
     assert _lib.lib().lkgd_gemm_f16(ctypes.byref(d), None) == -1      # LKGD_E_NULL
-    assert _lib.lib().lkgd_groupnorm_chunks(129, 320) == 3 and _lib.lib().lkgd_groupnorm_chunks(576, 1280) == 48
+    # small maps are cut down to 8-KiB chunks (12 rows of 320 channels, 8 rows of 1280); large ones keep the 32-KiB apply chunks
+    assert _lib.lib().lkgd_groupnorm_chunks(129, 320) == 11 and _lib.lib().lkgd_groupnorm_chunks(576, 1280) == 72
+    assert _lib.lib().lkgd_groupnorm_chunks(14 * 9216, 320) == (14 * 9216 + 50) // 51
 
 
 def test_scheduler_tables_equal_reference_kat():
