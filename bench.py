@@ -45,9 +45,11 @@ def parse():
     ap.add_argument("--inference-steps", type=int, default=25)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet config (plumbing checks only; not a valid number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-full", action="store_true",
-                    help="cpu_baseline: time ONE full configs[1] forward of the fp32 oracle on this box's host in this run "
-                         "(minutes) instead of quoting the committed round-2 measurement beside the bounded live sample")
+    ap.add_argument("--no-cpu-full", action="store_true",
+                    help="cpu_baseline: do NOT time the full configs[1] forward of the fp32 oracle in this run (~4 minutes in a "
+                         "CPU-only child process after the GPU work); quote the committed round-2 measurement beside a bounded sample")
+    ap.add_argument("--cpu-full", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--cpu-full-timeout", type=int, default=330, help="wall-clock guard of the full CPU forward, seconds")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed) VAE encode / decode measurement")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--lk", action="store_true",
@@ -104,14 +106,70 @@ def kernels_sha16():
     return h.hexdigest()[:16]
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_full_forward_child(args):
+    """ONE full configs[1] forward of the fp32 oracle (89.69 TFLOP) on this box's host cores, in a fresh CPU-only child
+    process (tools/cpu_full_forward.py: imports torch + oracle/, never touches the GPU), started AFTER the GPU work so that
+    its threads do not take the launch thread's core inside the timed region.  Wall-clock guard: the child is killed at
+    --cpu-full-timeout seconds and None is returned (the caller falls back to the bounded sample + the quoted measurement)."""
+    import subprocess
+    env = dict(os.environ, FRAMES=str(args.frames), LAT_H=str(args.height // 8), LAT_W=str(args.width // 8),
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", LKGD_PROGRESS_STDERR="1")
+    t0 = time.time()
+    print(f"bench.py: timing ONE full configs[1] forward of the fp32 oracle on the host cores (CPU-only child process, guard "
+          f"{args.cpu_full_timeout} s; --no-cpu-full skips it) ...", file=sys.stderr, flush=True)
+    try:     # the child's per-block progress lines go to this process's stderr: a multi-minute leg that is never silent
+        p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "cpu_full_forward.py")], env=env, stdout=subprocess.PIPE,
+                           stderr=None, timeout=args.cpu_full_timeout, text=True)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the full CPU forward did not finish within {args.cpu_full_timeout} s - falling back", file=sys.stderr)
+        return None
+    if p.returncode != 0:
+        print(f"bench.py: tools/cpu_full_forward.py exited with {p.returncode} - falling back", file=sys.stderr)
+        return None
+    for ln in reversed(p.stdout.strip().splitlines()):
+        if ln.startswith("{"):
+            rec = json.loads(ln)
+            rec["child_wall_s"] = round(time.time() - t0, 1)
+            return rec
+    return None
+
+
 def cpu_baseline(args):
-    """fp32 oracle on the host cores, bounded sample: ONE forward of the real-shaped UNet on half the C1 geometry
-    (CFG batch 2 x 2 frames x 32x32 latent = 1.19 algorithmic TFLOP, 8-27 s on the boxes seen so far), extrapolated to
-    the C2 metric by FLOPs."""
+    """the fp32 CPU oracle (oracle/, "port") timed on this box's host cores.  Default: ONE full configs[1] UNet forward (the
+    whole workload of one Euler step: ~190 s on the GPU boxes seen so far) measured by THIS run in a CPU-only child process,
+    x 25 steps / 14 frames.  Fallback (--no-cpu-full, or the guard fired): a bounded 1.19-TFLOP sample measured here beside
+    the full-forward figure quoted from profiles/r02_cpu_full_forward.json, and the line says which it is."""
+    cores = torch.get_num_threads()
+    if args.tiny:
+        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "tiny config (invalid)"}
+    if not args.no_cpu_full:
+        full = cpu_full_forward_child(args)
+        if full and full.get("seconds"):
+            fps_full = args.frames / (args.inference_steps * float(full["seconds"]))
+            return {"value": round(fps_full, 6),
+                    "unit": "frames/s (one full configs[1] UNet forward of the fp32 oracle, measured, x 25 steps / 14 frames)",
+                    "cores": full.get("threads", cores), "kind": "port", "value_source": "measured by this run",
+                    "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
+                    "sample": f"ONE full configs[1] forward (CFG 2 x {args.frames} frames x {args.height // 8}x{args.width // 8} latent, "
+                              f"{UNET_TFLOP_C2:.2f} TFLOP) of the fp32 oracle (torch eager) in {float(full['seconds']):.1f} s = "
+                              f"{full.get('tflops')} TFLOP/s on {full.get('threads', cores)} host threads, in a CPU-only child process "
+                              f"after the GPU work ({full.get('child_wall_s')} s with the model build)",
+                    "finite": full.get("finite")}
     from oracle import unet as ou
     t0 = time.time()
     with torch.device("meta"):
-        o = ou.UNetSpatioTemporalConditionControlNetModel(ou.SVD_CONFIG if not args.tiny else ou.TINY_CONFIG)
+        o = ou.UNetSpatioTemporalConditionControlNetModel(ou.SVD_CONFIG)
     o = o.to_empty(device="cpu")
     with torch.no_grad():
         for p in o.parameters():
@@ -131,40 +189,32 @@ def cpu_baseline(args):
     with torch.no_grad():
         o(x, torch.tensor(1.0), enc, added_time_ids=ids, return_dict=False)
     dt = time.time() - t0
-    tflop_sample = 2.37 / 2 if not args.tiny else 0.0
-    cores = torch.get_num_threads()
-    if args.tiny:
-        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "tiny config (invalid)"}
+    tflop_sample = 2.37 / 2
     tflops = tflop_sample / dt
     fps = args.frames / (args.inference_steps * UNET_TFLOP_C2 / tflops)
     full, full_src = None, None
-    if getattr(args, "cpu_full", False):       # time the ONE full configs[1] forward of the oracle in THIS run (minutes)
-        sys.path.insert(0, os.path.join(REPO, "tools"))
-        from cpu_full_forward import run_full_forward
-        full = run_full_forward(args.frames, args.height // 8, args.width // 8, verbose=False)
-        full_src = "measured by this run (--cpu-full)"
-    else:            # ... or quote the one timed on a GPU box's host in round 2 (tools/cpu_full_forward.py, committed log)
-        try:
-            with open(os.path.join(REPO, "profiles", "r02_cpu_full_forward.json")) as f:
-                full = json.load(f)
-            full_src = "NOT measured by this run: quoted from profiles/r02_cpu_full_forward.json (tools/cpu_full_forward.py " \
-                       "on a GPU box's host, round 2); this run measured `live_sample` only - pass --cpu-full to time it here"
-        except (OSError, ValueError):
-            pass
+    try:        # the full forward timed on a GPU box's host in round 2 (tools/cpu_full_forward.py, committed log)
+        with open(os.path.join(REPO, "profiles", "r02_cpu_full_forward.json")) as f:
+            full = json.load(f)
+        full_src = "NOT measured by this run: quoted from profiles/r02_cpu_full_forward.json (tools/cpu_full_forward.py " \
+                   "on a GPU box's host, round 2); this run measured `live_sample` only" + (
+                       " (--no-cpu-full)" if args.no_cpu_full else " - its full forward hit the wall-clock guard")
+    except (OSError, ValueError):
+        pass
     live = (f"oracle fp32 (torch eager), one UNet forward of the real-shaped SVD UNet at CFG-batch 2 x 2 frames x 32x32 latent "
             f"(half of config 1's geometry, {tflop_sample:.2f} TFLOP) in {dt:.1f} s = {tflops:.3f} TFLOP/s on {cores} threads "
             f"(os.cpu_count={os.cpu_count()}) -> {fps:.6f} C2-equivalent frames/s by FLOPs; model build {t_build:.0f} s not counted")
     if full and full.get("seconds"):
-        # the stated baseline is the MEASURED full configs[1] forward (the small sample under-feeds the host's threads and
-        # extrapolates 3x low); the bounded sample of this run is kept beside it
+        # the small sample under-feeds the host's threads and extrapolates 3x low: the quoted full forward is the stated value
         fps_full = args.frames / (args.inference_steps * float(full["seconds"]))
         return {"value": round(fps_full, 6), "unit": "frames/s (one full configs[1] UNet forward of the fp32 oracle, measured, x 25 steps / 14 frames)",
-                "cores": full.get("threads", cores), "kind": "port", "value_source": full_src,
+                "cores": full.get("threads", cores), "kind": "port", "value_source": full_src, "cpu_model": _cpu_model(),
                 "sample": f"ONE full configs[1] forward (CFG 2 x 14 frames x 72x128 latent, {UNET_TFLOP_C2:.2f} TFLOP) of the fp32 oracle "
                           f"in {float(full['seconds']):.1f} s on {full.get('threads', cores)} host threads",
                 "live_sample": live, "live_sample_value": round(fps, 6)}
     return {"value": round(fps, 6), "unit": "frames/s (C2-equivalent, extrapolated by algorithmic FLOPs)",
-            "cores": cores, "kind": "port", "value_source": "measured by this run (bounded sample)", "sample": live}
+            "cores": cores, "kind": "port", "value_source": "measured by this run (bounded sample)", "cpu_model": _cpu_model(),
+            "sample": live}
 
 
 def vae_stages(dev, args, latents, loop_s_per_clip):

@@ -149,10 +149,9 @@ int lkgd_groupnorm_stats_cols(const float* cs0, int32_t blk0, int32_t ldcs0, int
 int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
                          int64_t nsamples, int64_t rows_per_sample, const float* stats, const float* gamma,
                          const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);
-/* the whole F.group_norm (+ F.silu) of a tensor in one call: out = silu?(groupnorm(x)); statistics pass + apply pass, the
- * finalize step inside the apply pass's prologue where a sample has few chunk partials (two launches instead of three; the
- * same numbers as lkgd_groupnorm_stats + lkgd_groupnorm_apply, bit for bit).  `partial` as above; `stats` (nsamples*32*2
- * floats) is scratch the three-launch form writes (mean, rstd) to. */
+/* the whole F.group_norm (+ F.silu) of a tensor in one call: out = silu?(groupnorm(x)) = lkgd_groupnorm_stats followed by
+ * lkgd_groupnorm_apply (the same three launches, the same numbers); `partial` as above, `stats` (nsamples*32*2 floats) receives
+ * (mean, rstd). */
 int lkgd_groupnorm_silu(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1, int64_t nsamples,
                         int64_t rows_per_sample, float eps, float* partial, float* stats, const float* gamma,
                         const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);
@@ -443,7 +442,6 @@ const char* lkgd_version(void);
  *                                       2 = wherever it is legal (S >= 128; S % 128 != 0 runs its masked form); 0 = by sequence length
  *      lkgd_debug_set_gn_apply_kb(kb) / lkgd_debug_set_gn_stats_kb(kb)   GroupNorm chunk sizes in KiB (>= 32)
  *      lkgd_debug_set_gn_target_wgs(n)  workgroups a GroupNorm pass aims at on small maps (chunks shrink to 8 KiB); 1 = fixed sizes
- *      lkgd_debug_set_gn_fuse_finalize(on)   lkgd_groupnorm_silu: 0 = always the three-launch form
  * ------------------------------------------------------------------------------------------------------------- */
 void lkgd_debug_set_gemm_variant(int32_t v);
 void lkgd_debug_set_gemm_splitk(int32_t on);
@@ -456,7 +454,6 @@ void lkgd_debug_set_attn_pipe(int32_t mode);
 void lkgd_debug_set_gn_apply_kb(int32_t kb);
 void lkgd_debug_set_gn_stats_kb(int32_t kb);
 void lkgd_debug_set_gn_target_wgs(int32_t n);
-void lkgd_debug_set_gn_fuse_finalize(int32_t on);
 
 #ifdef __cplusplus
 }

@@ -114,7 +114,6 @@ SYMBOLS = {
     "lkgd_debug_set_gn_apply_kb": (None, [_i32]),
     "lkgd_debug_set_gn_stats_kb": (None, [_i32]),
     "lkgd_debug_set_gn_target_wgs": (None, [_i32]),
-    "lkgd_debug_set_gn_fuse_finalize": (None, [_i32]),
 }
 
 _lib = None
@@ -137,6 +136,9 @@ def lib() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         if os.environ.get("LKGD_ATTN_PIPE"):     # A/B measurements only (same-box bench pairs): 1 = never the software-pipelined
             l.lkgd_debug_set_attn_pipe(int(os.environ["LKGD_ATTN_PIPE"]))   # attention program, 2 = wherever legal
+        for env, fn in (("LKGD_GN_TARGET_WGS", "lkgd_debug_set_gn_target_wgs"), ("LKGD_GEMM_VARIANT", "lkgd_debug_set_gemm_variant")):
+            if os.environ.get(env):              # A/B measurements only
+                getattr(l, fn)(int(os.environ[env]))
         _lib = l
     return _lib
 

@@ -266,10 +266,7 @@ extern "C" int lkgd_tattn_block_c320(const void* x, int32_t ldx, const void* wst
         hipFuncSetAttribute((const void*)tattn_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS) != hipSuccess)
       return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = lkgd_cu_count();      // cached per device (common.h)
   tb_params p;
   p.rowbias = (const half_t*)rowbias; p.ldrb = ldrb;
   p.rb_d1 = rb_d1 > 0 ? rb_d1 : 1; p.rb_m1 = rb_m1; p.rb_d2 = rb_d2 > 0 ? rb_d2 : 1; p.rb_md = rb_md > 0 ? rb_md : 1; p.rb_c0 = rb_c0;

@@ -355,10 +355,7 @@ extern "C" int lkgd_tattn_front(const void* x, int32_t ldx, const void* wpack, c
     if (hipFuncSetAttribute((const void*)tattn_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS) != hipSuccess)
       return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = lkgd_cu_count();      // cached per device (common.h)
   const int panels_per_clip = HW / 16;
   const long long npanels = (long long)B * panels_per_clip;
   if (npanels > 0x7fffffffLL) return LKGD_E_SHAPE;

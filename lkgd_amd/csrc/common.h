@@ -71,6 +71,20 @@ struct lkgd_device_once {
   }
   void done(int dev) { mask.fetch_or(1ull << dev, std::memory_order_release); }
 };
+// CU count of the current device, queried once per device ordinal (hipGetDeviceProperties is a slow host call; the launchers
+// of the persistent kernels need the count on every launch to size their grids); 256 if the query fails
+static inline int lkgd_cu_count() {
+  static std::atomic<int> cus_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+  int cus = cus_of[dev].load(std::memory_order_relaxed);
+  if (!cus) {
+    hipDeviceProp_t prop;
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus_of[dev].store(cus, std::memory_order_relaxed);
+  }
+  return cus;
+}
 #define LKGD_DEVICE_ONCE_BEGIN                     \
   {                                                \
     static lkgd_device_once once_;                 \

@@ -285,10 +285,7 @@ extern "C" int lkgd_ff_fused_c320(const void* x, int32_t ldx, int64_t T, const v
         hipFuncSetAttribute((const void*)ff_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess)
       return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = lkgd_cu_count();      // cached per device (common.h)
   const long long npanels = (T + FF_WAVES * 32 - 1) / (FF_WAVES * 32);
   ff_params p;
   p.x = (const half_t*)x; p.ldx = ldx; p.T = T;

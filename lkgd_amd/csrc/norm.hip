@@ -203,16 +203,14 @@ __global__ void gn_finalize_sums_kernel(const float* sums, long long n, double i
   stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// FIN: the (mean, rstd) of the sample's 32 groups are reduced from the statistics pass's chunk partials in the prologue -
-// the arithmetic of gn_finalize_kernel (one wave per group, the same lane -> chunk map and butterfly: bitwise the same
-// numbers) - instead of being read from `stats`: one launch less per GroupNorm where a sample has few chunks.
-template <bool FIN>
+// (round 5 measured the finalize step inside this kernel's prologue - every workgroup reducing the chunk partials of its
+// sample, bitwise the finalize kernel's numbers, one launch less per GroupNorm - on the maps of a rank of 8 and of the full
+// forward: 22.2 vs 21.6 ms and 89.7 vs 88.9 ms per forward, SLOWER both times, as round 3 had found at full size;
+// profiles/r05_gn_ab.txt.  Removed again.)
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0, int ld0, const half_t* x1, int c1,
                                                        int ld1, long long rows_per_sample, const float* stats,
                                                        const float* gamma, const float* beta, int silu,
-                                                       half_t* out, int ldo, int GN_ROWS, const float* partial,
-                                                       int nchunks_stats, double inv_count, float eps) {
-  __shared__ float s_stats[GN_GROUPS * 2];
+                                                       half_t* out, int ldo, int GN_ROWS) {
   const int C = c0 + c1;
   const GnMap mp = gn_map(C);
   const int t = threadIdx.x;
@@ -222,21 +220,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0,
   if (r1 > rows_per_sample) r1 = rows_per_sample;
   const long long base = sample * rows_per_sample;
   const int gs = C / GN_GROUPS;
-  if (FIN) {
-    const int lane = t & 63, wv = t >> 6;
-    for (int g = wv; g < GN_GROUPS; g += 4) {
-      double sa, sb;
-      gn_reduce_pair(partial, nchunks_stats, sample, g, lane, sa, sb);
-      if (lane == 0) {
-        double mean = sa * inv_count;
-        double var = sb * inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_stats[g * 2 + 0] = (float)mean;
-        s_stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-      }
-    }
-    __syncthreads();
-  }
   for (int slot = 0; slot < mp.nslot; ++slot) {
     int cv, rp;
     if (mp.nslot == 1) { rp = t / mp.C8; cv = t - rp * mp.C8; if (rp >= mp.rows_par) continue; }
@@ -250,9 +233,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, int c0,
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int g = (cv * 8 + e) / gs;
-        float2_t mr;
-        if (FIN) { mr[0] = s_stats[g * 2]; mr[1] = s_stats[g * 2 + 1]; }
-        else mr = *(const float2_t*)(stats + (sample * GN_GROUPS + g) * 2);
+        const float2_t mr = *(const float2_t*)(stats + (sample * GN_GROUPS + g) * 2);
         const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
         A[e] = mr[1] * ga;
         B[e] = be - mr[0] * A[e];
@@ -361,47 +342,21 @@ extern "C" int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, con
   if (ldo % 8 || !aligned16(out)) return LKGD_E_ALIGN;
   const int ra = gn_rows(c0 + c1, rows_per_sample, nsamples);
   int nchunks = (int)((rows_per_sample + ra - 1) / ra);
-  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, stats, gamma,
-                     beta, silu, (half_t*)out, ldo, ra, (const float*)nullptr, 0, 0.0, 0.f);
+                     beta, silu, (half_t*)out, ldo, ra);
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 
-// The whole GroupNorm (+ SiLU) of a tensor in one call: statistics pass, then the apply pass with the finalize step in its
-// prologue where a sample has at most GN_FIN_MAX_CHUNKS chunk partials (two launches), else statistics + finalize + apply.
-#define GN_FIN_MAX_CHUNKS 256
-static int gn_fuse_finalize = 1;
-extern "C" void lkgd_debug_set_gn_fuse_finalize(int on) { gn_fuse_finalize = on != 0; }
+// The whole GroupNorm (+ SiLU) of a tensor in one C call: statistics pass, finalize, apply pass (three launches; what a
+// caller saves is two trips through its own call layer)
 extern "C" int lkgd_groupnorm_silu(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
                                    int64_t nsamples, int64_t rows_per_sample, float eps, float* partial, float* stats,
                                    const float* gamma, const float* beta, int32_t silu, void* out, int32_t ldo,
                                    lkgd_stream_t stream) {
-  int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
+  int rc = lkgd_groupnorm_stats(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample, eps, partial, stats, stream);
   if (rc) return rc;
-  if (!partial || !stats || !gamma || !beta || !out) return LKGD_E_NULL;
-  if (ldo % 8 || !aligned16(out)) return LKGD_E_ALIGN;
-  const int C = c0 + c1;
-  const int rs = gn_rows_stats(C, rows_per_sample, nsamples);
-  const int nchunks = (int)((rows_per_sample + rs - 1) / rs);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample, partial,
-                     nchunks, rs);
-  const double inv = 1.0 / ((double)rows_per_sample * (double)(C / GN_GROUPS));
-  const int ra = gn_rows(C, rows_per_sample, nsamples);
-  const int achunks = (int)((rows_per_sample + ra - 1) / ra);
-  if (gn_fuse_finalize && nchunks <= GN_FIN_MAX_CHUNKS) {
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(achunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample,
-                       (const float*)nullptr, gamma, beta, silu, (half_t*)out, ldo, ra, (const float*)partial, nchunks, inv,
-                       eps);
-  } else {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(8, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream, partial,
-                       nchunks, inv, eps, stats);
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(achunks, (unsigned)nsamples), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)x0, c0, ld0, (const half_t*)x1, c1, ld1, (long long)rows_per_sample,
-                       (const float*)stats, gamma, beta, silu, (half_t*)out, ldo, ra, (const float*)nullptr, 0, 0.0, 0.f);
-  }
-  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+  return lkgd_groupnorm_apply(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample, stats, gamma, beta, silu, out, ldo, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------- LayerNorm

@@ -172,10 +172,7 @@ static int ln_qkv_launch(const void* x, int32_t ldx, int64_t T, const void* wstr
     if (hipFuncSetAttribute((const void*)ln_qkv_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, QK_LDS) != hipSuccess)
       return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = lkgd_cu_count();      // cached per device (common.h)
   const long long npanels = (T + QK_WAVES * 32 - 1) / (QK_WAVES * 32);
   qk_params p;
   p.x = (const half_t*)x; p.ldx = ldx; p.T = T; p.wstream = (const char*)wstream; p.eps = eps;

@@ -12,7 +12,11 @@ Correctness notes
   * every rank keeps the full latents (replicated, 1 MB) and the UNet weights; activations are sharded;
   * the temporal cross-attention context of diffusers 0.27 interleaves the CFG halves' embeddings over pixels
     (App. C11), so every rank evaluates the cross-attention bias table for BOTH embeddings;
-  * uneven frame slices (14 = 4+4+3+3) are padded to equal counts for RCCL's all-gather and compacted afterwards.
+  * uneven frame slices (14 = 4+4+3+3) are padded to equal counts for RCCL's all-gather and compacted afterwards;
+  * several clips per call (round 5; the [start, end] pair of the trans pipelines with the `patch` joint-attention hooks,
+    UNet batch [u_x, u_y, c_x, c_y]): a rank holds its frame slice of EVERY clip of its CFG half, so the entries a joint
+    hook couples (masks [0,1,0,1]) are on one rank and the hook needs no exchange of its own; the temporal exchanges run
+    entry by entry.  8 GPUs = CFG x (4,4,3,3) frames x 2 clips per rank.
 """
 from __future__ import annotations
 
@@ -29,41 +33,63 @@ from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, fr
 
 
 class ShardInfo:
-    """what lkgd_amd.unet.Ctx needs to know about this rank's slice"""
+    """what lkgd_amd.unet.Ctx needs to know about this rank's slice.  A rank holds ``entries`` batch entries (one clip: 1;
+    the [start, end] pair of the trans pipelines: 2 per CFG half, rows (entry, frame, pixel)); the exchanges below run entry by
+    entry - every entry's frames are a contiguous [f_local, HW, C] block of the token matrix."""
 
-    def __init__(self, plan: ShardPlan, frame_group, HW_getter=None):
+    def __init__(self, plan: ShardPlan, frame_group, entries: int = 1):
         self.plan = plan
         self.group = frame_group
         self.F_total = plan.num_frames
         self.f0 = plan.f0
-        self.B_total = plan.cfg_groups       # one clip: batch entries == CFG halves
-        self.b0 = plan.cfg_index
+        self.set_entries(entries)
+
+    def set_entries(self, entries: int) -> None:
+        """batch entries per CFG half (clips of the call)"""
+        self.entries = entries
+        self.B_total = self.plan.cfg_groups * entries      # batch entries of the whole job
+        self.b0 = self.plan.cfg_index * entries            # first global batch entry of this rank
+
+    def _per_entry(self, x: torch.Tensor, f):
+        """apply f to each entry's contiguous row block and stack the results"""
+        n = self.entries
+        if n == 1:
+            return f(x)
+        rows = x.shape[0] // n
+        return torch.cat([f(x[e * rows:(e + 1) * rows]) for e in range(n)])
 
     def gather(self, local: torch.Tensor) -> torch.Tensor:
-        """[f_local*HW, C] tokens -> [F*HW, C] over the frame group"""
+        """[entries*f_local*HW, C] tokens -> [entries*F*HW, C] over the frame group"""
         fl = self.plan.f_local
-        x = local.reshape(fl, -1, local.shape[-1])
-        full = gather_frames(x, self.plan, self.group)
-        return full.reshape(-1, local.shape[-1])
+
+        def one(t):
+            return gather_frames(t.reshape(fl, -1, t.shape[-1]), self.plan, self.group).reshape(-1, t.shape[-1])
+        return self._per_entry(local, one)
 
     def to_pixels(self, local: torch.Tensor, HW: int) -> torch.Tensor:
-        """[f_local*HW, C] tokens (own frames, all pixels) -> [F*px_local, C] (all frames, own pixel slice): all-to-all"""
-        x = frames_to_pixels(local.reshape(self.plan.f_local, HW, local.shape[-1]), self.plan, self.group)
-        return x.reshape(-1, local.shape[-1])
+        """[entries*f_local*HW, C] tokens (own frames, all pixels) -> [entries*F*px_local, C] (all frames, own pixel slice): all-to-all"""
+        def one(t):
+            return frames_to_pixels(t.reshape(self.plan.f_local, HW, t.shape[-1]), self.plan, self.group).reshape(-1, t.shape[-1])
+        return self._per_entry(local, one)
 
     def to_frames(self, x: torch.Tensor, HW: int) -> torch.Tensor:
         """inverse of to_pixels"""
         F = self.plan.num_frames
-        out = pixels_to_frames(x.reshape(F, x.shape[0] // F, x.shape[-1]), self.plan, HW, self.group)
-        return out.reshape(-1, x.shape[-1])
+
+        def one(t):
+            return pixels_to_frames(t.reshape(F, t.shape[0] // F, t.shape[-1]), self.plan, HW, self.group).reshape(-1, t.shape[-1])
+        return self._per_entry(x, one)
 
     def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
         return allreduce_sums(sums, self.plan, self.group)
 
     def halo(self, buf: torch.Tensor) -> torch.Tensor:
-        """[(f_local+2)*HW, C] tokens with the own frames in the middle -> neighbours' boundary frames in the two end slots"""
-        fl = self.plan.f_local
-        exchange_halo(buf.reshape(fl + 2, -1, buf.shape[-1]), self.plan, self.group)
+        """[entries*(f_local+2)*HW, C] tokens with the own frames in the middle of every entry's block -> neighbours' boundary
+        frames in the two end slots of every block"""
+        fl, n = self.plan.f_local, self.entries
+        rows = buf.shape[0] // n
+        for e in range(n):
+            exchange_halo(buf[e * rows:(e + 1) * rows].reshape(fl + 2, -1, buf.shape[-1]), self.plan, self.group)
         return buf
 
 
@@ -104,11 +130,11 @@ class DistDenoiser:
         unet, sch = pipe.unet, pipe.scheduler
         dev = unet.device
         B, F, _, H, W = latents.shape
-        if B != 1:
-            raise LkgdHipError("sharded denoising handles one clip (batch 1) per call")
         cfg = 2 if max_guidance_scale > 1 else 1
         if cfg != plan.cfg_groups and not (cfg == 2 and plan.cfg_groups == 1):
             raise LkgdHipError("shard plan was built for classifier-free guidance; got guidance <= 1")
+        if F != plan.num_frames:
+            raise LkgdHipError(f"the shard plan was built for {plan.num_frames} frames, the latents carry {F}")
         HW = H * W
         latents = latents.to(dev).contiguous()
         image_latents = image_latents.to(device=dev, dtype=torch.float16).contiguous()
@@ -119,28 +145,37 @@ class DistDenoiser:
             enc = unet.fused_embedding(enc, domain_features.to(dev), flow_features.to(dev))
         ids = added_time_ids.to(dev)
         vpred = sch.config.prediction_type == "v_prediction"
+        from . import patch as _patch
+        _patch.set_joint_attention(unet, enable=True)           # reference :555 (no-op unless the model is patched)
         fl, f0, fmax = plan.f_local, plan.f0, plan.f_max
+        # batch entries of the UNet batch are ordered (CFG half, clip): [u_x, u_y, c_x, c_y] for the [start, end] pair of the
+        # trans pipelines (pipeline_stable_video_diffusion_trans.py:549).  A CFG-parallel rank holds the B clips of ITS half -
+        # the pairs the `patch` joint hooks couple (masks [0,1,0,1], utils/util.py:600-606) live on one rank, so the joint
+        # attention needs no exchange of its own - and, under frame sharding, the same frame slice of every one of them.
         if plan.cfg_groups == 2:
-            b_local, ids_local = 1, ids[plan.cfg_index:plan.cfg_index + 1]
+            b_local, e0 = B, plan.cfg_index * B
         else:
-            b_local, ids_local = cfg, ids
-        self.shard.B_total = 2 if plan.cfg_groups == 2 else cfg     # batch entries of the whole job (CFG halves)
-        if b_local != 1 and plan.frame_shards > 1:
-            raise LkgdHipError("frame sharding without CFG-parallel needs guidance off (one batch entry per rank)")
-        send = torch.zeros(fmax * HW * b_local, 4, dtype=torch.float16, device=dev)
-        buf = torch.empty(plan.world * fmax * HW * b_local, 4, dtype=torch.float16, device=dev)
-        noise_full = torch.empty(cfg * F * HW, 4, dtype=torch.float16, device=dev)
+            b_local, e0 = cfg * B, 0
+        ids_local = ids[e0:e0 + b_local]
+        self.shard.set_entries(b_local)
+        if controlnet_condition is not None and B != 1:
+            raise LkgdHipError("the sharded ControlNet loop handles one clip per call")
+        send = torch.zeros(b_local, fmax * HW, 4, dtype=torch.float16, device=dev)
+        buf = torch.empty(plan.world, b_local, fmax * HW, 4, dtype=torch.float16, device=dev)
+        noise_full = torch.empty(cfg * B * F * HW, 4, dtype=torch.float16, device=dev)
         # step-invariant addresses for everything the forward reads, so its launch list can be replayed
-        tok = torch.empty(cfg * F * HW, 8, dtype=torch.float16, device=dev)
+        tok = torch.empty(cfg * B * F * HW, 8, dtype=torch.float16, device=dev)
         t_dev = torch.zeros(b_local, dtype=torch.float32, device=dev)
         ids_local = ids_local.to(torch.float32).contiguous()
         enc = enc.to(torch.float16).contiguous()
-        if plan.cfg_groups == 2:
-            r0 = (plan.cfg_index * F + f0) * HW
+        if plan.frame_shards == 1:
+            tok_local, pick = tok[e0 * F * HW:(e0 + b_local) * F * HW], None
+        elif b_local == 1:
+            r0 = (e0 * F + f0) * HW
             tok_local, pick = tok[r0:r0 + fl * HW], None
         else:
-            tok_local = torch.empty(cfg * fl * HW, 8, dtype=torch.float16, device=dev)
-            pick = (tok_local.reshape(cfg, fl, HW, 8), tok.reshape(cfg, F, HW, 8)[:, f0:f0 + fl])
+            tok_local = torch.empty(b_local * fl * HW, 8, dtype=torch.float16, device=dev)
+            pick = (tok_local.reshape(b_local, fl, HW, 8), tok.reshape(cfg * B, F, HW, 8)[e0:e0 + b_local, f0:f0 + fl])
         ctrl_local = None
         if controlnet_condition is not None:
             if getattr(pipe, "controlnet", None) is None:
@@ -176,24 +211,14 @@ class DistDenoiser:
             else:
                 noise_local = forward()
             # ---- exchange the noise prediction over all ranks (padded equal counts), compact, replicate the update
-            if plan.cfg_groups == 2:
-                send[:fl * HW].copy_(noise_local)
-                all_gather_into(buf, send)
-                for r in range(plan.world):
-                    ci, si = divmod(r, plan.frame_shards)
-                    n, fs = plan.splits[si], sum(plan.splits[:si])
-                    noise_full[(ci * F + fs) * HW:(ci * F + fs + n) * HW].copy_(
-                        buf[r * fmax * HW:r * fmax * HW + n * HW])
-            else:
-                nl = noise_local.reshape(cfg, fl * HW, 4)
-                sv = send.reshape(cfg, fmax * HW, 4)
-                sv[:, :fl * HW].copy_(nl)
-                all_gather_into(buf, send)
-                bv = buf.reshape(plan.world, cfg, fmax * HW, 4)
-                nf = noise_full.reshape(cfg, F * HW, 4)
-                for r in range(plan.world):
-                    n, fs = plan.splits[r], sum(plan.splits[:r])
-                    nf[:, fs * HW:(fs + n) * HW].copy_(bv[r, :, :n * HW])
+            send[:, :fl * HW].copy_(noise_local.reshape(b_local, fl * HW, 4))
+            all_gather_into(buf.reshape(-1, 4), send.reshape(-1, 4))
+            nf = noise_full.reshape(cfg * B, F * HW, 4)
+            for r in range(plan.world):
+                ci, si = divmod(r, plan.frame_shards)
+                n, fs = plan.splits[si], sum(plan.splits[:si])
+                er = ci * b_local if plan.cfg_groups == 2 else 0
+                nf[er:er + b_local, fs * HW:(fs + n) * HW].copy_(buf[r, :, :n * HW])
             ops.cfg_euler_step(noise_full, latents, guidance, cfg, sigma, sigma_next, v_prediction=vpred)
         ops.GEMM_EVENTS = events_all
         sch._step_index = num_inference_steps

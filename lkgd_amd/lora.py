@@ -315,15 +315,19 @@ class EntryPlan:
     ``runs``: [(b0, b1)] maximal runs of consecutive batch entries on which EVERY wrapped projection of the model sees the
     same adapter subset; ``adapters(wrapper, run_index, via_partner)`` -> tuple of adapter names for that run."""
 
-    def __init__(self, layers: List[Tuple[str, Linear]], B: int, partner: Optional[List[int]]):
+    def __init__(self, layers: List[Tuple[str, Linear]], B: int, partner: Optional[List[int]],
+                 B_total: Optional[int] = None, b0: int = 0):
+        """``B`` entries of this forward = entries [b0, b0 + B) of a UNet batch of ``B_total`` (a CFG-parallel rank holds one CFG
+        half of the call's batch, lkgd_amd/dist_run.py; the lora masks describe the WHOLE batch); ``partner`` is local"""
         self.B = B
+        B_total = B if B_total is None else B_total
         self._dec: Dict[int, List[Tuple[str, ...]]] = {}     # id(wrapper) -> per batch entry adapter tuple
         self._dec_p: Dict[int, List[Tuple[str, ...]]] = {}   # the same seen through the partner permutation
         sig = [[] for _ in range(B)]
         for name, m in layers:
             masked = getattr(m, "_lkgd_masked", False)
             per = []
-            for b in range(B):
+            for b in range(b0, b0 + B):
                 act = []
                 for a in m.active_adapters:
                     if a not in m.lora_A:
@@ -337,9 +341,9 @@ class EntryPlan:
                                            "(patch.set_patch_lora_mask) - the reference raises KeyError here")
                     mk = masks[a]
                     L = len(mk)
-                    if B % L:
-                        raise LkgdHipError(f"lora_mask of length {L} does not divide the UNet batch of {B} entries")
-                    if bool(mk[b // (B // L)]):
+                    if B_total % L:
+                        raise LkgdHipError(f"lora_mask of length {L} does not divide the UNet batch of {B_total} entries")
+                    if bool(mk[b // (B_total // L)]):
                         act.append(a)
                 per.append(tuple(act))
             self._dec[id(m)] = per
@@ -360,9 +364,9 @@ class EntryPlan:
         return (self._dec_p if via_partner else self._dec)[id(wrapper)][self.runs[run][0]]
 
 
-def entry_plan(unet, B: int, partner: Optional[List[int]]) -> Optional[EntryPlan]:
+def entry_plan(unet, B: int, partner: Optional[List[int]], B_total: Optional[int] = None, b0: int = 0) -> Optional[EntryPlan]:
     """None when the model has no LoRA wrappers (the common case: nothing changes on the hot path)"""
     layers = lora_layers(unet)
     if not layers:
         return None
-    return EntryPlan(layers, B, partner)
+    return EntryPlan(layers, B, partner, B_total, b0)

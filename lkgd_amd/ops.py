@@ -325,9 +325,18 @@ def ff_fused(x: torch.Tensor, wstream: torch.Tensor, b2: torch.Tensor, out: torc
              res2: Optional[torch.Tensor] = None, r2: float = 0.0) -> torch.Tensor:
     """out = s_acc * (FF(LN(x')) + x') + r2 * res2 with x' = x + rowbias[(row // d1) % md]  (lkgd_ff_fused_c320)"""
     _req(x, torch.float16, "x"); _req(wstream, torch.float16, "wstream"); _req(b2, torch.float32, "b2")
+    _req(out, torch.float16, "out")
+    if x.shape[1] != 320 or out.shape != x.shape:
+        raise _lib.LkgdHipError("ff_fused: x / out must be [T, 320] token matrices of the same row count")
+    if res2 is not None:
+        _req(res2, torch.float16, "res2")
+        if res2.shape[0] != x.shape[0]:
+            raise _lib.LkgdHipError("ff_fused: res2 must hold one row per token")
+    if rowbias is not None:
+        _req(rowbias, torch.float16, "rowbias")
     d1, m1, d2, md = (rowmap if rowmap is not None else (1, 1, 1, 1))[:4]
-    if rowbias is not None and (m1 != 1 or d2 != 1):
-        raise _lib.LkgdHipError("ff_fused: only (row // d1) % md row maps")
+    if rowbias is not None and (m1 != 1 or d2 != 1 or (len(rowmap) > 4 and rowmap[4] != 0)):
+        raise _lib.LkgdHipError("ff_fused: only (row // d1) % md row maps (no c0 term)")
     ev = GEMM_EVENTS        # a GEMM-family launch for bench.py's roofline line: 2 T (2560 x 320 + 320 x 1280) algorithmic FLOP
     if ev is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -383,8 +392,8 @@ def tattn_block(x: torch.Tensor, wstream: torch.Tensor, bo: torch.Tensor, out: t
     of every pixel, the out-projection and the residual in one launch (lkgd_tattn_block_c320); x / out: [B*F*HW, 320]"""
     _req(x, torch.float16, "x"); _req(wstream, torch.float16, "wstream"); _req(out, torch.float16, "out")
     _req(bo, torch.float32, "bo")
-    if x.shape[0] != B * F * HW or out.shape[0] != x.shape[0]:
-        raise _lib.LkgdHipError("tattn_block: x / out must hold B * F * HW rows")
+    if x.shape[0] != B * F * HW or out.shape[0] != x.shape[0] or x.shape[1] != 320 or out.shape[1] != 320:
+        raise _lib.LkgdHipError("tattn_block: x / out must be [B * F * HW, 320] token matrices")
     d1, m1, d2, md = rowmap[:4] if rowmap is not None else (1, 0, 1, 1)
     c0 = rowmap[4] if rowmap is not None and len(rowmap) > 4 else 0
     if rowbias is not None:

@@ -20,6 +20,7 @@ from typing import Callable, Dict, List, Optional, Union
 import torch
 
 from . import ops
+from . import trace as _trace
 from ._lib import LkgdHipError
 from .image_ops import resize_with_antialiasing
 from .image_processor import VaeImageProcessor, tensor2vid
@@ -273,8 +274,12 @@ class StableVideoDiffusionPipeline:
                 raise ValueError("controlnet_condition must carry cfg*batch entries")
             ctrl = controlnet_condition.to(device=dev, dtype=torch.float16).contiguous()
         fwd = self._graphed_forward(cfg * B, F, H, W, enc, ids) if (self.use_hip_graph and ctrl is None) else None
+        timers = _trace.StepTimers() if _trace.STEP_TIMERS else None      # LKGD_STEP_TIMERS=1: device ms per Euler step
+        self.last_step_timers = timers
         for i, t in enumerate(sch.timesteps_host):
             sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
+            _trace.push(f"euler_step_{i}")                                  # roctx range (LKGD_ROCTX=1), else a no-op
+            t_ev = timers.start() if timers is not None else None
             if fwd is not None:
                 ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=fwd.tok)
                 noise_tok = fwd.run(t)
@@ -286,11 +291,16 @@ class StableVideoDiffusionPipeline:
                                                                   controlnet_cond_scale)
                 noise_tok, _ = unet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids, down, mid)
             ops.cfg_euler_step(noise_tok, latents, guidance_dev, cfg, sigma, sigma_next, v_prediction=vpred)
+            if timers is not None:
+                timers.stop(t_ev)
+            _trace.pop()
             if callback_on_step_end is not None:
                 kw = {k: {"latents": latents}[k] for k in callback_on_step_end_tensor_inputs}
                 out = callback_on_step_end(self, i, t, kw)
                 latents = out.pop("latents", latents) if isinstance(out, dict) else latents
         sch._step_index = num_inference_steps
+        if timers is not None:
+            timers.finish()
         return latents
 
     def _latents_for_decode(self, latents: torch.Tensor) -> torch.Tensor:

@@ -54,6 +54,16 @@ class _RecordingLib:
             if name == "lkgd_gemm_f16":
                 d = args[0]._obj
                 flop = 2.0 * d.M * d.N * (72 if d.mode == 3 else d.K)
+            # the fused kernels of the GEMM family, with the FLOP formulas ops.ff_fused / ops.tattn_block / ops.ln_qkv use for
+            # the eager path's events (bench.py's roofline line counts the same launches replayed or not)
+            elif name == "lkgd_ff_fused_c320":
+                flop = 2.0 * args[2] * (2560 * 320 + 320 * 1280)
+            elif name in ("lkgd_ln_qkv_c320", "lkgd_ln_qkv_c640"):
+                c = 320 if name.endswith("c320") else 640
+                flop = 2.0 * args[2] * 3 * c * c
+            elif name == "lkgd_tattn_block_c320":
+                rows = args[13] * args[14] * args[15]
+                flop = 2.0 * rows * (960 * 320 + 320 * 320) + 4.0 * rows * 16 * 320
             plan.calls.append((fn, args[:-1], name, flop))   # the last argument of every launch is the stream
             return rc
         return call
@@ -71,6 +81,11 @@ class Plan:
         self.calls.append((None, f, "py", None))
 
     def run(self, gemm_events=None):
+        from . import trace
+        with trace.range_("replayed_launch_list"):       # roctx range (LKGD_ROCTX=1): the per-block ranges exist in eager runs only
+            return self._run(gemm_events)
+
+    def _run(self, gemm_events=None):
         stream = None
         for fn, args, name, flop in self.calls:
             if fn is None:

@@ -35,6 +35,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import trace as _trace
 from ._lib import LkgdHipError
 from .packing import pack_conv3x3, pack_conv3x3_c8, pack_ff_fused, pack_geglu, pack_linear, pack_tconv3
 
@@ -90,8 +91,6 @@ class Ctx:
         self.f0 = shard.f0 if shard is not None else 0
         self.B_total = shard.B_total if shard is not None else B
         self.b0 = shard.b0 if shard is not None else 0
-        if self.frames_sharded and B != 1:
-            raise LkgdHipError("frame sharding supports one batch entry per rank")
         self.temb_all: Optional[torch.Tensor] = None      # [B, sum C] fp16
         self.xb_all: Optional[torch.Tensor] = None        # [B, sum C] fp16
         self.joint_blocks = None
@@ -399,6 +398,7 @@ class BasicTransformerBlock(nn.Module):
         pk.var = {}                         # masked-LoRA weight variants, built on demand (_attn_variant)
         self._pk = pk
 
+    @_trace.traced("spatial_transformer_block")
     def run(self, ctx: Ctx, h: torch.Tensor) -> torch.Tensor:
         pk, T, Cc = self._pk, h.shape[0], h.shape[1]
         heads = self.attn1.heads
@@ -549,6 +549,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         pk.var = {}
         self._pk = pk
 
+    @_trace.traced("temporal_transformer_block")
     def run(self, ctx: Ctx, h_s: torch.Tensor, posemb: torch.Tensor, alpha: float, order: str) -> torch.Tensor:
         """h_s: output of the spatial block; returns alpha*h_s + (1-alpha)*temporal(h_s + posemb[f])"""
         pk, T, Cc = self._pk, h_s.shape[0], h_s.shape[1]
@@ -556,6 +557,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         m1 = _ff_ln(ctx, pk.ffin, h_s, rowbias=posemb, rowmap=fmap)               # ff_in(norm_in(m0)) + m0, m0 = h_s + pos
         att = ctx.new(T, Cc)
         va = None
+        att_joint = None       # attn1n's attention output where the sharded paths below compute it (frames on several GPUs)
         # LayerNorm + QKV + attention over the frames in one kernel where it exists (C = 320: the 72x128 level); the joint
         # branch reads the normalised tokens again, masked LoRA runs per-entry weights, a sharded rank gathers frames: unfused
         joint = self.enable_joint_attention and hasattr(self, "attn1n")
@@ -603,21 +605,34 @@ class TemporalBasicTransformerBlock(nn.Module):
             # frames of the clip live on several GPUs: re-shard by PIXELS around the attention (all-to-all), so that this rank
             # holds all F frames of its pixel slice - LayerNorm, Q|K|V and the attention then run once per token, fused where
             # the kernel applies - and bring the attention output back to frame slices (lkgd_amd/dist.py)
-            m1p = ctx.shard.to_pixels(m1, ctx.HW)
+            m1p = ctx.shard.to_pixels(m1, ctx.HW)              # rows (entry, frame, pixel of this rank's slice)
             Tp, Ft = m1p.shape[0], ctx.F_total
-            pxl = Tp // Ft
+            pxl = Tp // (Ft * ctx.B)
             attp = ctx.new(Tp, Cc)
+            ln1p = None
             if ops.tattn_front_ok(Cc, self.attn1.heads, Ft, pxl):
                 if getattr(pk.a1, "wfront", None) is None:
                     from .packing import pack_tfront
                     pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
-                ops.tattn_front(m1p, pk.a1.wfront, pk.a1.bqkv, attp, 1, Ft, pxl, self.attn1.heads)
+                ops.tattn_front(m1p, pk.a1.wfront, pk.a1.bqkv, attp, ctx.B, Ft, pxl, self.attn1.heads)
             else:
                 ln1p = ops.layernorm(m1p, None, None, 1e-5)
                 qkv = ctx.new(Tp, 3 * Cc)
                 ops.gemm(ln1p, pk.a1.wqkv, qkv, M=Tp, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
-                ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], attp, 1, Ft, pxl, self.attn1.heads)
+                ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], attp, ctx.B, Ft, pxl, self.attn1.heads)
             att = ctx.shard.to_frames(attp, ctx.HW)
+            if joint:
+                # the joint branch in the same pixel layout: all frames of the partner ENTRY's pixels are on this rank (a rank
+                # holds its slice of every clip of its CFG half), so attn1n needs no exchange beyond bringing its output back
+                if ctx.temporal_partner is None:
+                    raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
+                if ln1p is None:
+                    ln1p = ops.layernorm(m1p, None, None, 1e-5)
+                qkvj, attjp = ctx.new(Tp, 3 * Cc), ctx.new(Tp, Cc)
+                ops.gemm(ln1p, pk.a1n.wqkv, qkvj, M=Tp, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
+                ops.attn_temporal(qkvj[:, :Cc], qkvj[:, Cc:2 * Cc], qkvj[:, 2 * Cc:], attjp, ctx.B, Ft, pxl, self.attn1n.heads,
+                                  kv_b_map=ctx.temporal_partner)
+                att_joint = ctx.shard.to_frames(attjp, ctx.HW)
         else:
             # LKGD_TEMPORAL_GATHER=1: local queries against the keys / values of ALL frames.  The
             # normalised hidden states are gathered (C channels) and K|V projected here for every frame: half the
@@ -629,6 +644,14 @@ class TemporalBasicTransformerBlock(nn.Module):
             ops.gemm(ln1f, pk.a1.wqkv[Cc:], kvf, M=Tf, N=2 * Cc, K=Cc, bias=pk.a1.bqkv[Cc:])
             ops.attn_temporal(q, kvf[:, :Cc], kvf[:, Cc:], att, ctx.B, ctx.F_total, ctx.HW, self.attn1.heads,
                               Fq=ctx.F)
+            if joint:         # attn1n: local query frames against the partner entry's keys / values of ALL frames
+                if ctx.temporal_partner is None:
+                    raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
+                qj, kvj, att_joint = ctx.new(T, Cc), ctx.new(Tf, 2 * Cc), ctx.new(T, Cc)
+                ops.gemm(ln1, pk.a1n.wqkv[:Cc], qj, M=T, N=Cc, K=Cc, bias=pk.a1n.bqkv[:Cc])
+                ops.gemm(ln1f, pk.a1n.wqkv[Cc:], kvj, M=Tf, N=2 * Cc, K=Cc, bias=pk.a1n.bqkv[Cc:])
+                ops.attn_temporal(qj, kvj[:, :Cc], kvj[:, Cc:], att_joint, ctx.B, ctx.F_total, ctx.HW, self.attn1n.heads,
+                                  kv_b_map=ctx.temporal_partner, Fq=ctx.F)
         xtab = ctx.xb_all[:, pk.xoff:pk.xoff + Cc]
         if isinstance(order, tuple):
             xmap = order                      # explicit context-row map (tests drive single blocks this way)
@@ -652,27 +675,29 @@ class TemporalBasicTransformerBlock(nn.Module):
             _gemm_runs(ctx, att, m2, lambda i: (va[i].wo, va[i].bo, ctx.xb_runs[i][b_off:, pk.xoff:pk.xoff + Cc]),
                        N=Cc, K=Cc, rowmap=xmap, res1=m1)
         if self.enable_joint_attention and hasattr(self, "attn1n"):
-            m2 = self._joint(ctx, ln1, m2)
+            m2 = self._joint(ctx, ln1, m2, att_joint)
         if ctx.cross_Lk > 1:                  # literal attn2 over the time context (same row -> context map as the folded bias)
             m2 = _cross_literal(self, ctx, m2, xmap, ctx.b0 if order == "batch_major" else 0)
         # ff(norm3(m2)) + m2, then AlphaBlender with the spatial branch - one epilogue
         return _ff_ln(ctx, pk.ff, m2, s_acc=1.0 - alpha, res2=h_s, r2=alpha)
 
-    def _joint(self, ctx: Ctx, ln1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
-        """temporal joint branch (patch/patch.py:616-658): attn1n over the partner batch entry's frames"""
-        pk, T, Cc = self._pk, ln1.shape[0], ln1.shape[1]
+    def _joint(self, ctx: Ctx, ln1: Optional[torch.Tensor], m2: torch.Tensor, att: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """temporal joint branch (patch/patch.py:616-658): attn1n over the partner batch entry's frames; ``att``: the attention
+        output where the caller computed it already (frame-sharded ranks: over all frames, run())"""
+        pk, T, Cc = self._pk, m2.shape[0], m2.shape[1]
         if ctx.temporal_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
-        qkv = ctx.new(T, 3 * Cc)
         vj = None
-        if ctx.lora is None:
-            ops.gemm(ln1, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
-        else:
-            vj = [_attn_variant(self, "a1n", ctx, i, False) for i in range(len(ctx.lora.runs))]
-            _gemm_runs(ctx, ln1, qkv, lambda i: (vj[i].wqkv, vj[i].bqkv, None), N=3 * Cc, K=Cc)
-        att = ctx.new(T, Cc)
-        ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
-                          self.attn1n.heads, kv_b_map=ctx.temporal_partner)
+        if att is None:
+            qkv = ctx.new(T, 3 * Cc)
+            if ctx.lora is None:
+                ops.gemm(ln1, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
+            else:
+                vj = [_attn_variant(self, "a1n", ctx, i, False) for i in range(len(ctx.lora.runs))]
+                _gemm_runs(ctx, ln1, qkv, lambda i: (vj[i].wqkv, vj[i].bqkv, None), N=3 * Cc, K=Cc)
+            att = ctx.new(T, Cc)
+            ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
+                              self.attn1n.heads, kv_b_map=ctx.temporal_partner)
         out = ctx.new(T, Cc)
         if vj is None:   # post folded in; joint_scale is not applied here
             ops.gemm(att, pk.jw, out, M=T, N=Cc, K=Cc, bias=pk.jb, res1=m2)
@@ -730,6 +755,7 @@ class TransformerSpatioTemporalModel(nn.Module):
             self._posemb[ctx.F_total] = e
         return e
 
+    @_trace.traced("transformer")
     def run(self, ctx: Ctx, x: torch.Tensor) -> torch.Tensor:
         pk, T, Cc = self._pk, x.shape[0], x.shape[1]
         if self._alpha is None:
@@ -796,6 +822,7 @@ class SpatioTemporalResBlock(nn.Module):
         pk.alpha = None
         self._pk = pk
 
+    @_trace.traced("resblock")
     def run(self, ctx: Ctx, x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x = cat(x0, x1) on channels (skip connection folded into the consumers' gathers)"""
         pk = self._pk
@@ -841,14 +868,18 @@ class SpatioTemporalResBlock(nn.Module):
             return ops.groupnorm_silu(x, None, ctx.B, ctx.F * ctx.HW, *affine, eps)
         sums = ctx.shard.allreduce(ops.groupnorm_sums(x, None, ctx.B, ctx.F * ctx.HW))
         stats = ops.groupnorm_finalize(sums, float(ctx.F_total) * ctx.HW * (x.shape[1] // 32), eps)
-        # (only the clip's two end slots are padding; every other halo slot is overwritten by the exchange)
-        buf = torch.empty((ctx.F + 2) * ctx.HW, x.shape[1], dtype=torch.float16, device=x.device)
+        # every batch entry gets its own [F + 2]-frame block (the Conv3d's gather addresses entry b at b * (F + 2) * HW);
+        # only the clip's two end slots are padding, every other halo slot is overwritten by the exchange
+        blk, rows = (ctx.F + 2) * ctx.HW, ctx.F * ctx.HW
+        buf = torch.empty(ctx.B * blk, x.shape[1], dtype=torch.float16, device=x.device)
         plan = ctx.shard.plan
-        if plan.shard_index == 0:
-            buf[:ctx.HW].zero_()
-        if plan.shard_index == plan.frame_shards - 1:
-            buf[(ctx.F + 1) * ctx.HW:].zero_()
-        ops.groupnorm_apply(x, None, ctx.B, ctx.F * ctx.HW, stats, *affine, True, buf[ctx.HW:(ctx.F + 1) * ctx.HW])
+        for b in range(ctx.B):
+            if plan.shard_index == 0:
+                buf[b * blk:b * blk + ctx.HW].zero_()
+            if plan.shard_index == plan.frame_shards - 1:
+                buf[(b + 1) * blk - ctx.HW:(b + 1) * blk].zero_()
+            ops.groupnorm_apply(x[b * rows:(b + 1) * rows], None, 1, rows, stats[b:b + 1], *affine, True,
+                                buf[b * blk + ctx.HW:(b + 1) * blk - ctx.HW])
         return ctx.shard.halo(buf)
 
 
@@ -916,6 +947,7 @@ class CrossAttnDownBlockSpatioTemporal(_BlockBase):
             for _ in range(num_layers)])
         self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
 
+    @_trace.traced("block")
     def run(self, ctx, h):
         outs = []
         for r, a in zip(self.resnets, self.attentions):
@@ -937,6 +969,7 @@ class DownBlockSpatioTemporal(_BlockBase):
             for i in range(num_layers)])
         self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
 
+    @_trace.traced("block")
     def run(self, ctx, h):
         outs = []
         for r in self.resnets:
@@ -963,6 +996,7 @@ class UNetMidBlockSpatioTemporal(_BlockBase):
                                            transformer_layers_per_block, cross_attention_dim)
             for _ in range(num_layers)])
 
+    @_trace.traced("block")
     def run(self, ctx, h):
         h = self.resnets[0].run(ctx, h)
         for a, r in zip(self.attentions, self.resnets[1:]):
@@ -985,6 +1019,7 @@ class UpBlockSpatioTemporal(_BlockBase):
                                    out_channels, temb_channels, eps) for i in range(num_layers)])
         self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
 
+    @_trace.traced("block")
     def run(self, ctx, h, skips: List[torch.Tensor]):
         for r in self.resnets:
             h = r.run(ctx, h, skips.pop())
@@ -1010,6 +1045,7 @@ class CrossAttnUpBlockSpatioTemporal(_BlockBase):
             for _ in range(num_layers)])
         self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
 
+    @_trace.traced("block")
     def run(self, ctx, h, skips: List[torch.Tensor]):
         for r, a in zip(self.resnets, self.attentions):
             h = a.run(ctx, r.run(ctx, h, skips.pop()))
@@ -1185,6 +1221,8 @@ class _UNetBase(nn.Module):
         if self.device.type != "cuda":
             raise LkgdHipError("lkgd_amd UNet runs on MI355X only: move the module to cuda before forward()")
         self._temb_reg, self._cross_reg = [], []
+        for name, mod in self.named_modules():          # dotted paths for the roctx ranges (lkgd_amd/trace.py)
+            mod._trace_name = name or type(self).__name__
         self.time_embedding.pack()
         self.add_embedding.pack()
         for blk in list(self.down_blocks) + [self.mid_block] + ([] if self._encoder_only else list(self.up_blocks)):
@@ -1277,6 +1315,23 @@ class _UNetBase(nn.Module):
             return
         info = getattr(self, "_tome_info", None)
         flip = bool(info and info["args"].get("flip", False))
+        if ctx.shard is not None:
+            # a sharded rank holds the batch entries [b0, b0 + B) of the call: the mask of the whole UNet batch is cut to them.  The
+            # reference pairs the i-th unmasked with the i-th masked entry of the WHOLE batch (patch.py:466-468); that pairing
+            # stays inside the rank when everything in front of its slice and the slice itself hold as many masked as unmasked
+            # entries - true for the loader's [0,1,0,1] over [u_x, u_y, c_x, c_y] split into CFG halves
+            full = [bool(v) for v in torch.as_tensor(mask).tolist()]
+            if ctx.B_total % len(full):
+                raise LkgdHipError("joint_attn_mask length must divide the UNet batch")
+            full = [v for v in full for _ in range(ctx.B_total // len(full))]
+            head, own = full[:ctx.b0], full[ctx.b0:ctx.b0 + ctx.B]
+            if sum(head) * 2 != len(head) or sum(own) * 2 != len(own):
+                raise LkgdHipError("joint attention under sharding: a rank's batch entries must hold whole (masked, unmasked) "
+                                   f"pairs; mask {full}, entries {ctx.b0}..{ctx.b0 + ctx.B - 1}")
+            if flip and ctx.frames_sharded:
+                raise LkgdHipError("joint attention with flip=True pairs frame f with frame F-1-f of the partner clip, which "
+                                   "lives on another rank under frame sharding")
+            mask = own
 
         def partner(n_rows, group):
             m = torch.as_tensor(mask, dtype=torch.bool).repeat_interleave(n_rows // len(mask))
@@ -1332,17 +1387,21 @@ class _UNetBase(nn.Module):
         """channels-last entry: input tokens [B*F*H*W, 8] -> (noise tokens [B*F*H*W, 4], ctx).  This is what
         lkgd_amd.pipeline calls between the glue kernels (no NCHW conversions inside the loop)."""
         self.prepare()
+        with _trace.range_("unet_forward"):
+            return self._forward_tokens(tokens, B, F, H, W, timestep, encoder_hidden_states, added_time_ids,
+                                        down_block_additional_residuals, mid_block_additional_residual, shard)
+
+    def _forward_tokens(self, tokens, B, F, H, W, timestep, encoder_hidden_states, added_time_ids,
+                        down_block_additional_residuals, mid_block_additional_residual, shard):
         ctx = Ctx(B, F, H, W, self.device, shard)
         pk = self._pk
         self._time_embed(ctx, timestep, added_time_ids)
-        if shard is not None and getattr(self, "_joint_attn_mask", None) is not None:
-            raise LkgdHipError("joint attention (patch API) pairs batch entries and is not available under sharding")
         self._joint_maps(ctx)
         if pk.has_lora:
-            if shard is not None:
-                raise LkgdHipError("LoRA wrappers under sharding: merge them first (lkgd_amd.lora.merge_lora)")
+            if ctx.frames_sharded:
+                raise LkgdHipError("LoRA wrappers under frame sharding: merge them first (lkgd_amd.lora.merge_lora)")
             from . import lora as _lora
-            ctx.lora = _lora.entry_plan(self, ctx.B, ctx.entry_partner)
+            ctx.lora = _lora.entry_plan(self, ctx.B, ctx.entry_partner, ctx.B_total, ctx.b0)
         self._cross_tables(ctx, encoder_hidden_states)
         h = ctx.new(ctx.T, pk.w_in.shape[0])
         ops.gemm(tokens, pk.w_in, h, M=ctx.T, N=pk.w_in.shape[0], K=128, bias=pk.b_in, mode=ops.A_CONV3X3_C8, Cin=8,

@@ -114,6 +114,27 @@ def _worker(rank, world, port, frames, q):
         rec.run()
         ok = ok and torch.equal(got2, full * 2.0)
         ok = ok and torch.equal(sums2, torch.full((1, 32, 2), float(10 * sum(range(1, world + 1)))))
+        # several batch entries per rank (round 5: both clips of the [start, end] pair on every rank of a CFG half): the exchanges
+        # run entry by entry on the (entry, frame, pixel) row layout of the token matrices
+        from lkgd_amd.dist_run import ShardInfo
+        sh = ShardInfo(plan, None, entries=2)
+        ok = ok and sh.B_total == 2 and sh.b0 == 0
+        HW, C = 6, 3
+        if HW >= world:
+            both = torch.arange(2 * frames * HW * C, dtype=torch.float32).reshape(2, frames, HW, C)
+            mine2 = both[:, plan.f0:plan.f0 + plan.f_local].reshape(-1, C).contiguous()
+            full2 = sh.gather(mine2)
+            ok = ok and torch.equal(full2, both.reshape(-1, C))
+            px = pixel_splits(HW, world)
+            p0 = sum(px[:plan.shard_index])
+            xp2 = sh.to_pixels(mine2, HW)
+            ok = ok and torch.equal(xp2, both[:, :, p0:p0 + px[plan.shard_index]].reshape(-1, C))
+            ok = ok and torch.equal(sh.to_frames(xp2, HW), mine2)
+            hb3 = torch.zeros(2, plan.f_local + 2, HW, C)
+            hb3[:, 1:plan.f_local + 1] = both[:, plan.f0:plan.f0 + plan.f_local]
+            sh.halo(hb3.reshape(-1, C))
+            pad2 = torch.cat([torch.zeros(2, 1, HW, C), both, torch.zeros(2, 1, HW, C)], dim=1)
+            ok = ok and torch.equal(hb3, pad2[:, plan.f0:plan.f0 + plan.f_local + 2])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

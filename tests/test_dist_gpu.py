@@ -145,6 +145,73 @@ def _worker_cn(rank, world, port, frames, q):
         dist.destroy_process_group()
 
 
+def _worker_joint(rank, world, port, frames, q):
+    """the [start, end] pair of the trans pipelines under sharding (round 5): TWO clips per call, UNet batch [u_x, u_y, c_x, c_y],
+    `patch` joint-attention hooks on the spatial AND temporal blocks with masks [0,1,0,1] (utils/util.py:561-606,
+    patch/patch.py:438-501,:616-658); a rank holds its frame slice of both clips of its CFG half"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkgd_amd import patch
+        from lkgd_amd.dist_run import DistDenoiser
+        from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+        dev = torch.device("cuda", 0)
+        unet = _build(dev)
+        pipe = StableVideoDiffusionPipeline(unet=unet)
+        patch.apply_patch(pipe, with_temporal_block=True)
+        patch.initialize_joint_layers(pipe)
+        with torch.no_grad():                      # zero-initialised joint layers would be an identity branch
+            g = torch.Generator().manual_seed(12350)
+            for name, prm in unet.named_parameters():
+                if "attn1n" in name or "conv1n" in name:
+                    prm.copy_((torch.randn(prm.shape, generator=g) * (0.5 / max(prm.shape[-1], 1) ** 0.5)).to(prm))
+        unet.invalidate()
+        patch.set_joint_attention_mask(pipe, [0, 1, 0, 1])
+        lat0, img, emb, ids = _inputs(frames, True)
+        lat0 = torch.cat([lat0, 0.9 * lat0.flip(1)])                         # two clips
+        img = torch.stack([img[0], img[0], img[1], 0.8 * img[1]])            # [u_x, u_y, c_x, c_y]
+        emb = torch.stack([emb[0], emb[0], emb[1], 0.8 * emb[1]])
+        ids = ids[:1].repeat(4, 1)
+        pipe.scheduler.set_timesteps(2)
+        s0 = float(pipe.scheduler.init_noise_sigma)
+        runner = DistDenoiser(pipe, world, rank, frames, cfg=True)
+        args = lambda: ((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2, 1.0, 3.0)   # noqa: E731
+        out = runner.denoise(*args())
+        res = {"rank": rank, "out": out.float().cpu()}
+        if rank == 0:
+            res["ref"] = pipe.denoise(*args()).float().cpu()
+            patch.remove_patch(pipe)                         # the hooks off: the joint branch must matter to the result
+            res["plain"] = pipe.denoise(*args()).float().cpu()
+        q.put(_ship(res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames", [(2, 4), (4, 5)])
+def test_sharded_joint_pair_equals_single_process(world, frames):
+    """2 ranks: CFG halves x 2 clips each (the joint pairs are local, no frame exchange); 4 ranks: CFG x frame slices (3, 2) of
+    both clips - temporal GroupNorm sums, Conv3d halos and the pixel re-sharding run entry by entry, the temporal joint branch
+    runs in the re-sharded layout"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_joint, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = _collect(procs, q, world)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0 = [r for r in results if "ref" in r][0]
+    ref = r0["ref"]
+    assert ref.shape[0] == 2 and torch.isfinite(ref).all()
+    assert ((r0["plain"] - ref).norm() / ref.norm()).item() > 2e-2      # the joint branches really enter
+    for r in results:
+        rel = ((r["out"] - ref).norm() / ref.norm()).item()
+        assert rel <= 8e-3, f"rank {r['rank']}: sharded joint pair vs single process: relative L2 {rel:.3e}"
+
+
 @pytest.mark.parametrize("world,frames", [(2, 4), (4, 5)])
 def test_sharded_controlnet_lk_loop_equals_single_process(world, frames):
     ctx = mp.get_context("spawn")

@@ -268,10 +268,9 @@ def test_groupnorm_silu(ops, C0, C1, rows, ns):
 @pytest.mark.parametrize("C0,C1,rows,ns", [(320, 0, 9216, 4), (1280, 0, 576, 4), (1280, 1280, 144, 4), (640, 0, 4 * 2304, 1),
                                            (320, 0, 14 * 9216, 2), (128, 192, 77, 2)])
 def test_groupnorm_one_call_equals_three_launches_bitwise(C0, C1, rows, ns):
-    """lkgd_groupnorm_silu (statistics pass + apply pass with the finalize step in its prologue where a sample has few chunk
-    partials) against lkgd_groupnorm_stats + lkgd_groupnorm_apply on the maps of a frame-sharded rank and of the full
-    forward: the same bits, and both within tolerance of F.group_norm"""
-    from lkgd_amd import _lib, ops
+    """lkgd_groupnorm_silu against lkgd_groupnorm_stats + lkgd_groupnorm_apply on the maps of a frame-sharded rank (chunks cut
+    down to 8 KiB so that small maps still fill the CUs) and of the full forward: the same bits, within tolerance of F.group_norm"""
+    from lkgd_amd import ops
     g = torch.Generator().manual_seed(C0 + C1 + rows)
     C = C0 + C1
     x = _h(torch.randn(ns * rows, C, generator=g) * 2 + 0.5)
@@ -282,11 +281,6 @@ def test_groupnorm_one_call_equals_three_launches_bitwise(C0, C1, rows, ns):
     stats = ops.groupnorm_stats(x0, x1, ns, rows, 1e-5)
     three = ops.groupnorm_apply(x0, x1, ns, rows, stats, gamma, beta, True, torch.empty_like(one))
     assert torch.equal(one, three)
-    _lib.lib().lkgd_debug_set_gn_fuse_finalize(0)
-    try:
-        assert torch.equal(ops.groupnorm_silu(x0, x1, ns, rows, gamma, beta, 1e-5), one)
-    finally:
-        _lib.lib().lkgd_debug_set_gn_fuse_finalize(1)
     sub = slice(0, min(ns * rows, 20000))
     ref = F.silu(F.group_norm(x.float().reshape(ns, rows, C).permute(0, 2, 1), 32, gamma.cpu(), beta.cpu(), 1e-5))
     _close(one[sub], ref.permute(0, 2, 1).reshape(ns * rows, C)[sub], what="one-call groupnorm")

@@ -65,7 +65,9 @@ def run_full_forward(F=14, H=72, W=128, verbose=True):
 
 
 if __name__ == "__main__":
-    res = run_full_forward(int(os.environ.get("FRAMES", "14")), int(os.environ.get("LAT_H", "72")), int(os.environ.get("LAT_W", "128")))
+    # LKGD_PROGRESS_STDERR=1 (bench.py's child): progress lines on stderr, stdout carries the JSON record only
+    res = run_full_forward(int(os.environ.get("FRAMES", "14")), int(os.environ.get("LAT_H", "72")), int(os.environ.get("LAT_W", "128")),
+                           verbose=os.environ.get("LKGD_PROGRESS_STDERR", "0") != "1")
     print(json.dumps(res), flush=True)
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "cpu_full_forward.json"), "w") as f:
