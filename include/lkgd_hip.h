@@ -138,6 +138,11 @@ int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, const void* x1,
                         int64_t nsamples, int64_t rows_per_sample, float* partial, float* sums, lkgd_stream_t stream);
 int lkgd_groupnorm_finalize(const float* sums, int64_t nsamples, double count_per_group, float eps, float* stats,
                             lkgd_stream_t stream);
+/* ... from the raw sums of `nparts` ranks as ONE gathered buffer (the sums ride on the all-gather that carries the Conv3d halo
+ * frames, lkgd_amd/dist.py): part r's sums of sample s at parts + r*part_stride + s*sample_stride floats; added in rank order in
+ * fp64, so every rank of the frame group derives bitwise the same (mean, rstd) without an all-reduce */
+int lkgd_groupnorm_finalize_parts(const float* parts, int32_t nparts, int64_t part_stride, int64_t nsamples,
+                                  int64_t sample_stride, double count_per_group, float eps, float* stats, lkgd_stream_t stream);
 /* statistics of x = cat(x0[:, :c0], x1[:, :c1]) from the column sums their producing GEMMs left (lkgd_gemm_desc.colstats):
  * cs0 / cs1 = [rows / blk][ldcs / 2][2] fp32 (column pairs) with blk0 / blk1 rows per block (rows_per_sample must be a
  * multiple of both; channel counts and group size even);

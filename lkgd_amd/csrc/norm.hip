@@ -322,6 +322,39 @@ extern "C" int lkgd_groupnorm_sums(const void* x0, int32_t c0, int32_t ld0, cons
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 
+// the same finalize over the partial sums of several ranks, added in rank order in fp64 (every rank of a frame group runs it on
+// the same gathered buffer: identical statistics everywhere, no all-reduce): part r's sums of sample s start at
+// parts + r * part_stride + s * sample_stride (floats)
+__global__ void gn_finalize_parts_kernel(const float* parts, int nparts, long long part_stride, long long sample_stride,
+                                         long long n, double inv_count, float eps, float* stats) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long sample = i / GN_GROUPS;
+  const int g = (int)(i - sample * GN_GROUPS);
+  double a = 0.0, b = 0.0;
+  for (int r = 0; r < nparts; ++r) {
+    const float* p = parts + r * part_stride + sample * sample_stride + g * 2;
+    a += (double)p[0]; b += (double)p[1];
+  }
+  double mean = a * inv_count;
+  double var = b * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[i * 2] = (float)mean;
+  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" int lkgd_groupnorm_finalize_parts(const float* parts, int32_t nparts, int64_t part_stride, int64_t nsamples,
+                                             int64_t sample_stride, double count_per_group, float eps, float* stats,
+                                             lkgd_stream_t stream) {
+  if (!parts || !stats) return LKGD_E_NULL;
+  if (nparts <= 0 || nsamples <= 0 || part_stride < 0 || sample_stride < GN_GROUPS * 2 || !(count_per_group > 0.0)) return LKGD_E_SHAPE;
+  if (((uintptr_t)parts & 3u) != 0) return LKGD_E_ALIGN;
+  long long n = nsamples * GN_GROUPS;
+  hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts,
+                     nparts, (long long)part_stride, (long long)sample_stride, n, 1.0 / count_per_group, eps, stats);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
 extern "C" int lkgd_groupnorm_finalize(const float* sums, int64_t nsamples, double count_per_group, float eps,
                                        float* stats, lkgd_stream_t stream) {
   if (!sums || !stats) return LKGD_E_NULL;

@@ -303,6 +303,41 @@ def exchange_halo(buf: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tenso
     return buf
 
 
+#: temporal GroupNorm + Conv3d halo of a frame-sharded rank in ONE collective (default): the raw boundary frames and the
+#: GroupNorm partial sums travel in the same all-gather, every rank adds the sums in rank order and normalises the two halo
+#: frames it received itself.  LKGD_GN_HALO_SPLIT=1 (or the neighbour-only halo form, LKGD_HALO_P2P=1) selects the two-collective
+#: form: all-reduce of the sums, then the exchange of the NORMALISED boundary frames.
+GN_HALO_FUSED = os.environ.get("LKGD_GN_HALO_SPLIT", "0") != "1"
+SUMS_SLOT = 128      # fp16 elements reserved per batch entry for its [32, 2] fp32 sums
+
+
+def gather_boundary_frames_and_sums(first: List[torch.Tensor], last: List[torch.Tensor], sums: torch.Tensor, plan: ShardPlan,
+                                    group=None) -> torch.Tensor:
+    """One all-gather over the frame group carrying, per batch entry, this rank's first and last RAW frame (``first[b]`` /
+    ``last[b]``: contiguous [HW, C] fp16 views) and its GroupNorm partial sums (``sums`` [B, 32, 2] fp32).  Returns
+    got [k, B, 2 * HW * C + SUMS_SLOT] fp16: rank r's entry b = first frame | last frame | sums (as raw fp32 bits).  What
+    the two-collective form spends on a latency-bound 256-byte all-reduce per temporal GroupNorm (44 per UNet forward) is
+    gone, and the sums are added in rank order by every rank alike (lkgd_groupnorm_finalize_parts): the statistics are
+    bitwise the same on all ranks, whatever the collective library's reduction order."""
+    k, B = plan.frame_shards, len(first)
+    n = first[0].numel()
+    if sums.shape != (B, 32, 2) or sums.dtype != torch.float32 or any(t.numel() != n for t in first + last):
+        raise ValueError("gather_boundary_frames_and_sums: B frames of equal size and [B, 32, 2] fp32 sums")
+    W = 2 * n + SUMS_SLOT
+    send = torch.empty(B, W, dtype=first[0].dtype, device=first[0].device)
+    got = torch.empty(k, B, W, dtype=send.dtype, device=send.device)
+    sview = [send[b, 2 * n:].view(torch.float32) for b in range(B)]         # 64 floats each
+
+    def step():
+        for b in range(B):
+            send[b, :n].copy_(first[b].reshape(-1))
+            send[b, n:2 * n].copy_(last[b].reshape(-1))
+            sview[b].copy_(sums[b].reshape(-1))
+        all_gather_into(got.view(-1), send.view(-1), group)
+    _step(step)
+    return got
+
+
 def allreduce_sums(sums: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
     """sum of the GroupNorm partial sums over the frame group (fp32, a few hundred bytes)"""
     if plan.frame_shards > 1:

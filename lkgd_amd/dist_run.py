@@ -28,8 +28,8 @@ import torch.distributed as dist
 
 from . import ops, replay
 from ._lib import LkgdHipError
-from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, frames_to_pixels, gather_frames, make_plan,
-                   pixels_to_frames)
+from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, frames_to_pixels, gather_boundary_frames_and_sums,
+                   gather_frames, make_plan, pixels_to_frames)
 
 
 class ShardInfo:
@@ -82,6 +82,10 @@ class ShardInfo:
 
     def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
         return allreduce_sums(sums, self.plan, self.group)
+
+    def halo_raw(self, first, last, sums: torch.Tensor) -> torch.Tensor:
+        """the raw boundary frames and the GroupNorm partial sums of every entry in one all-gather (lkgd_amd/dist.py)"""
+        return gather_boundary_frames_and_sums(first, last, sums, self.plan, self.group)
 
     def halo(self, buf: torch.Tensor) -> torch.Tensor:
         """[entries*(f_local+2)*HW, C] tokens with the own frames in the middle of every entry's block -> neighbours' boundary

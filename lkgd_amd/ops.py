@@ -235,6 +235,18 @@ def groupnorm_finalize(sums: torch.Tensor, count_per_group: float, eps: float) -
     return stats
 
 
+def groupnorm_finalize_parts(parts: torch.Tensor, nparts: int, part_stride: int, nsamples: int, sample_stride: int,
+                              count_per_group: float, eps: float) -> torch.Tensor:
+    """(mean, rstd) [nsamples, 32, 2] from the raw sums of ``nparts`` ranks inside one gathered buffer (``parts``: a float32
+    view whose element r * part_stride + s * sample_stride starts rank r's sums of sample s), added in rank order"""
+    _req(parts, torch.float32, "parts")
+    stats = torch.empty(nsamples, 32, 2, dtype=torch.float32, device=parts.device)
+    check(_L().lkgd_groupnorm_finalize_parts(parts.data_ptr(), nparts, part_stride, nsamples, sample_stride,
+                                              float(count_per_group), eps, stats.data_ptr(), _stream()),
+          "lkgd_groupnorm_finalize_parts")
+    return stats
+
+
 def groupnorm_apply(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int, rows_per_sample: int,
                     stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, silu: bool,
                     out: torch.Tensor) -> torch.Tensor:

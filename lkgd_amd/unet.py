@@ -866,13 +866,39 @@ class SpatioTemporalResBlock(nn.Module):
         Conv3d (3,1,1) that follows needs +-1 frame; at the clip's ends the slot stays zero = the conv's padding)."""
         if not ctx.frames_sharded:
             return ops.groupnorm_silu(x, None, ctx.B, ctx.F * ctx.HW, *affine, eps)
-        sums = ctx.shard.allreduce(ops.groupnorm_sums(x, None, ctx.B, ctx.F * ctx.HW))
-        stats = ops.groupnorm_finalize(sums, float(ctx.F_total) * ctx.HW * (x.shape[1] // 32), eps)
+        from . import dist as _dist
         # every batch entry gets its own [F + 2]-frame block (the Conv3d's gather addresses entry b at b * (F + 2) * HW);
         # only the clip's two end slots are padding, every other halo slot is overwritten by the exchange
-        blk, rows = (ctx.F + 2) * ctx.HW, ctx.F * ctx.HW
-        buf = torch.empty(ctx.B * blk, x.shape[1], dtype=torch.float16, device=x.device)
+        HW, Cc = ctx.HW, x.shape[1]
+        blk, rows = (ctx.F + 2) * HW, ctx.F * HW
+        count = float(ctx.F_total) * HW * (Cc // 32)
+        buf = torch.empty(ctx.B * blk, Cc, dtype=torch.float16, device=x.device)
         plan = ctx.shard.plan
+        k, si = plan.frame_shards, plan.shard_index
+        if _dist.GN_HALO_FUSED and _dist._HALO_ALLGATHER:
+            # ONE collective per temporal GroupNorm + Conv3d: the raw boundary frames travel with the partial sums, every rank
+            # adds the sums in rank order and normalises the halo frames it received itself (lkgd_amd/dist.py)
+            sums = ops.groupnorm_sums(x, None, ctx.B, rows)
+            got = ctx.shard.halo_raw([x[b * rows:b * rows + HW] for b in range(ctx.B)],
+                                     [x[(b + 1) * rows - HW:(b + 1) * rows] for b in range(ctx.B)], sums)
+            n, W = HW * Cc, 2 * HW * Cc + _dist.SUMS_SLOT
+            parts = got.view(-1)[2 * n:].view(torch.float32)              # rank 0 / entry 0's sums; strides in floats below
+            stats = ops.groupnorm_finalize_parts(parts, k, ctx.B * W // 2, ctx.B, W // 2, count, eps)
+            for b in range(ctx.B):
+                st = stats[b:b + 1]
+                ops.groupnorm_apply(x[b * rows:(b + 1) * rows], None, 1, rows, st, *affine, True, buf[b * blk + HW:(b + 1) * blk - HW])
+                if si == 0:
+                    buf[b * blk:b * blk + HW].zero_()
+                else:             # the previous shard's LAST frame
+                    ops.groupnorm_apply(got[si - 1, b, n:2 * n].view(HW, Cc), None, 1, HW, st, *affine, True, buf[b * blk:b * blk + HW])
+                if si == k - 1:
+                    buf[(b + 1) * blk - HW:(b + 1) * blk].zero_()
+                else:             # the next shard's FIRST frame
+                    ops.groupnorm_apply(got[si + 1, b, :n].view(HW, Cc), None, 1, HW, st, *affine, True,
+                                        buf[(b + 1) * blk - HW:(b + 1) * blk])
+            return buf
+        sums = ctx.shard.allreduce(ops.groupnorm_sums(x, None, ctx.B, rows))
+        stats = ops.groupnorm_finalize(sums, count, eps)
         for b in range(ctx.B):
             if plan.shard_index == 0:
                 buf[b * blk:b * blk + ctx.HW].zero_()

@@ -135,6 +135,22 @@ def _worker(rank, world, port, frames, q):
             sh.halo(hb3.reshape(-1, C))
             pad2 = torch.cat([torch.zeros(2, 1, HW, C), both, torch.zeros(2, 1, HW, C)], dim=1)
             ok = ok and torch.equal(hb3, pad2[:, plan.f0:plan.f0 + plan.f_local + 2])
+        # temporal GroupNorm + Conv3d halo in ONE collective: raw boundary frames and the partial sums in the same all-gather
+        from lkgd_amd.dist import SUMS_SLOT, gather_boundary_frames_and_sums
+        HWc, Cc = 4, 8
+        xb = (torch.arange(2 * frames * HWc * Cc, dtype=torch.float32).reshape(2, frames, HWc, Cc) * 0.25 - 3.0).half()
+        mine3 = xb[:, plan.f0:plan.f0 + plan.f_local].contiguous()
+        sm = torch.arange(2 * 64, dtype=torch.float32).reshape(2, 32, 2) * (rank + 1) + 0.125
+        got = gather_boundary_frames_and_sums([mine3[b, 0] for b in range(2)], [mine3[b, -1] for b in range(2)], sm, plan)
+        n = HWc * Cc
+        ok = ok and tuple(got.shape) == (world, 2, 2 * n + SUMS_SLOT)
+        for r in range(world):
+            pr = make_plan(world, r, frames, cfg=False)
+            for b in range(2):
+                ok = ok and torch.equal(got[r, b, :n], xb[b, pr.f0].reshape(-1))
+                ok = ok and torch.equal(got[r, b, n:2 * n], xb[b, pr.f0 + pr.f_local - 1].reshape(-1))
+                want = torch.arange(2 * 64, dtype=torch.float32).reshape(2, 64)[b] * (r + 1) + 0.125
+                ok = ok and torch.equal(got[r, b, 2 * n:].view(torch.float32), want)     # fp32 bits survive the fp16 carrier
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -284,11 +284,15 @@ def test_sharded_dit_loop_equals_single_process(world):
 
 @pytest.mark.parametrize("world,frames,guidance_on,gather", [(2, 4, True, False), (4, 5, True, False), (2, 5, False, False),
                                                              (4, 6, False, False),
-                                                             (4, 6, False, True)])
+                                                             (4, 6, False, True), (4, 5, True, "split")])
 def test_sharded_loop_equals_single_process(world, frames, guidance_on, gather, monkeypatch):
     """gather = False: the temporal attention re-shards by pixels (all-to-all, the default; the 1x1 level of this tiny net has
-    fewer pixels than shards and keeps the gathered form); True: LKGD_TEMPORAL_GATHER=1, all-gather of the hidden states"""
-    if gather:
+    fewer pixels than shards and keeps the gathered form); True: LKGD_TEMPORAL_GATHER=1, all-gather of the hidden states;
+    "split": LKGD_GN_HALO_SPLIT=1, the temporal GroupNorm's sums all-reduced apart from the Conv3d halo exchange (two collectives
+    per temporal GroupNorm instead of the default one that carries raw boundary frames and sums together)"""
+    if gather == "split":
+        monkeypatch.setenv("LKGD_GN_HALO_SPLIT", "1")
+    elif gather:
         monkeypatch.setenv("LKGD_TEMPORAL_GATHER", "1")      # read by lkgd_amd.dist at import in the spawned ranks
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
