@@ -109,7 +109,7 @@ def test_hip_25_step_loop_headline_geometry_vs_reference_golden(golden_dir, c1_o
     """BASELINE.json configs[1] ITSELF, end to end (round 5): the reference's `__call__`
     (pipeline_stable_video_diffusion_trans.py:544-640) ran all 25 Euler steps of one clip x 14 frames x 576 x 1024 px (latent
     72 x 128), CFG 1 -> 3, with the real-width UNet in fp32 on the CPU (make_goldens.py::gen_loop25_headline, about two hours);
-    the fixture holds its latents after steps 5 / 10 / 15 / 20 / 25 and the returned latents (fp16) plus fp64 statistics of
+    the fixture holds its latents after steps 5 / 10 / 15 / 20 and the returned latents (fp16) plus fp64 statistics of
     every step.  The fp16 HIP loop - the very launches bench.py times - must stay within SURVEY.md 8d's gate at every stored
     step: relative L2 <= 5e-2, cosine >= 0.998."""
     from golden.fullres_cases import headline_inputs
