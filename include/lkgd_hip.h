@@ -424,6 +424,22 @@ int lkgd_attn_cross(const void* q, int32_t ldq, const void* k, int32_t ldk, cons
 int lkgd_attn_dense(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out, int32_t ldo,
                     int32_t nbatch, int32_t S, int32_t heads, int32_t head_dim, float scale, lkgd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * 17. LKGD latent-knowledge fuse (models/unet_spatio_temporal_condition.py:536-595, parameters :197-225):
+ *     e [B, 1024] CLIP embedding, d / f [Bd, 1000] domain / flow ViT logits (Bd = 1: broadcast over the batch, :544-546), all
+ *     fp32 -> out [B, 1024] fp16, the embedding that REPLACES the CLIP embedding (:595, :613).  Inside: F.interpolate(size = 1024,
+ *     "linear") of d / f, three Conv1d(1024 -> 256, k = 1, groups = 256), QuaternionLinear(1024 -> 512) on their concatenation with
+ *     the learned context, rfft (256 -> 129 bins) of each, abs / angle, QuaternionLinear(512 -> 256) on the magnitudes and on the
+ *     phases of bins 0..127, Linear(4 -> 1) x 2 on bin 128, irfft of the 257 bins (512 samples), fuse_sf = Linear(1024 -> 256) +
+ *     LeakyReLU(0.1) + Linear(256 -> 1024).  One workgroup per batch entry, fp32; step-invariant, so a caller runs it once per clip.
+ *     w[18], all fp32, matrices (in, out) row-major (quaternion layers as their expanded Hamilton matrices):
+ *       0-2 lconv / dconv / fconv [256][4]; 3 texts [256]; 4 fuse W [1024][512], 5 bias [512]; 6 texts_fft_mag [129], 7 texts_fft_pha
+ *       [129]; 8 fuse_fft_mag W [512][256], 9 bias; 10 fuse_fft_pha W, 11 bias; 12 fuse_fft_mag0 (4 weights + bias), 13 fuse_fft_pha0;
+ *       14 fuse_sf.0 W [1024][256], 15 bias; 16 fuse_sf.2 W [256][1024], 17 bias.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lkgd_lk_fuse(const float* e, const float* d, const float* f, int32_t B, int32_t Bd, const float* const* w, void* out,
+                 int32_t ldo, lkgd_stream_t stream);
+
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
 

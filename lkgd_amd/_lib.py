@@ -102,6 +102,7 @@ SYMBOLS = {
     "lkgd_vit_patchify": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "lkgd_gelu_tanh": (_i32, [_vp, _vp, _i64, _vp]),
     "lkgd_gated_add": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "lkgd_lk_fuse": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lkgd_version": (C.c_char_p, []),
     # debug / measurement knobs (process-global, not thread-safe: include/lkgd_hip.h, last section)
     "lkgd_debug_set_gemm_variant": (None, [_i32]),

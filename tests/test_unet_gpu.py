@@ -300,3 +300,31 @@ def test_forward_with_trained_like_weight_statistics(lk):
     rel, mx = _gate(out, ref, "trained-like statistics", rel_tol=max(1e-2, 8 * floor), abs_tol=0.25 * ref.abs().max().item())
     print(f"\ntrained-like weights ({'LK' if lk else 'stock'}): rel L2 {rel:.2e}, max abs {mx:.2e} of {ref.abs().max():.1f}; "
           f"input-rounding floor of the fp32 oracle {floor:.2e}")
+
+
+@pytest.mark.parametrize("B,Bd", [(2, 1), (2, 2), (4, 1), (1, 1)])
+def test_lk_fuse_kernel_vs_oracle(B, Bd):
+    """the latent-knowledge fuse as ONE hand-written launch (lkgd_lk_fuse, round 5; until then ATen / rocFFT / hipBLASLt ops)
+    against the fp32 oracle's restatement of unet_spatio_temporal_condition.py:536-595, which unet_wiring.safetensors pins on
+    the reference's own forward: interpolation, grouped convs, quaternion linears, 256-point DFT, abs / angle, the 257-bin
+    inverse, fuse_sf; broadcast of one feature row over the batch"""
+    from oracle import unet as ou
+    from lkgd_amd import unet as pu
+    from lkgd_amd.lk_fuse import lk_fuse
+    o = ou.init_weights_(ou.UNetSpatioTemporalConditionModel(ou.TINY_CONFIG), WSEED + 60)
+    m = pu.UNetSpatioTemporalConditionModel(pu.UNetConfig(**ou.TINY_CONFIG.__dict__))
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.half().to(DEV)
+    g = torch.Generator().manual_seed(WSEED + 61)
+    e = torch.randn(B, 1, 1024, generator=g)
+    d, f = 3.0 * torch.randn(Bd, 1, 1000, generator=g), 3.0 * torch.randn(Bd, 1, 1000, generator=g)
+    with torch.no_grad():
+        dd, ff = (d, f) if Bd == B else (d.expand(B, 1, 1000), f.expand(B, 1, 1000))
+        for p in o.parameters():                    # the HIP model holds fp16-rounded parameters
+            p.copy_(p.half().float())
+        ref = o.lk_fuse(e, dd, ff)
+    out = lk_fuse(m, e.to(DEV), d.to(DEV), f.to(DEV))
+    assert out.shape == (B, 1, 1024) and out.dtype == torch.float16
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item() + 1e-3, f"lk fuse: max abs err {err:.3e} of {ref.abs().max():.3f}"
+    assert torch.equal(lk_fuse(m, e.to(DEV), d.to(DEV), f.to(DEV)), out)
