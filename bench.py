@@ -57,7 +57,8 @@ def parse():
                          "CLIP embedding (not the headline workload)")
     ap.add_argument("--joint", action="store_true",
                     help="the `patch` joint-attention hooks (utils/util.py:561-606): TWO clips per call (the [start, end] pair of "
-                         "the trans pipelines), masks [0,1,0,1], spatial + temporal joint branch (not the headline workload)")
+                         "the trans pipelines), masks [0,1,0,1], spatial + temporal joint branch (not the headline workload); with "
+                         "--gpus N a rank holds its frame slice of both clips of its CFG half")
     ap.add_argument("--cogvideox", action="store_true",
                     help="configs[4]: the CogVideoX-2B image-to-video DiT loop (49 frames x 720x480 -> 13 latent frames x 60x90, CFG, "
                          "DDIM; NOT the headline workload, single GPU); a 'step' is one clip of --inference-steps DiT steps")
@@ -419,8 +420,6 @@ def main():
     lat0, img, emb, ids = synthetic_inputs(dev, args.frames, h, w)
     nclips = 1
     if args.joint:
-        if distributed:
-            raise SystemExit("--joint is a single-GPU option")
         from lkgd_amd import patch
         patch.apply_patch(pipe, with_temporal_block=True)
         patch.initialize_joint_layers(pipe)

@@ -20,6 +20,7 @@ from typing import Callable, Dict, List, Optional, Union
 import torch
 
 from . import ops
+from . import replay as _replay
 from . import trace as _trace
 from ._lib import LkgdHipError
 from .image_ops import resize_with_antialiasing
@@ -74,6 +75,8 @@ class StableVideoDiffusionPipeline:
         self.use_hip_graph = False   # opt-in: eager launches are already hidden behind GPU work on one GPU, and bench.py times
                                      # individual GEMM launches with events, which a graph replay cannot expose
         self._graph = None
+        #: replay the step's forward from a recorded launch list (denoise(); LKGD_NO_REPLAY=1 = walk the modules every step)
+        self.use_replay = __import__("os").environ.get("LKGD_NO_REPLAY", "0") != "1"
 
     # ---- loading (DiffusionPipeline.from_pretrained [EXT]; call sites run_models/run_inference_svd.py:166-168,
     #      utils/util.py:536) --------------------------------------------------------------------------------------
@@ -274,6 +277,27 @@ class StableVideoDiffusionPipeline:
                 raise ValueError("controlnet_condition must carry cfg*batch entries")
             ctrl = controlnet_condition.to(device=dev, dtype=torch.float16).contiguous()
         fwd = self._graphed_forward(cfg * B, F, H, W, enc, ids) if (self.use_hip_graph and ctrl is None) else None
+        # The step's forward is shape-static over the Euler steps: the first step runs for real and is RECORDED as a flat list of
+        # C-ABI launches (lkgd_amd/replay.py), the other 24 replay it between in-place updates of its inputs (token buffer,
+        # timestep) - bit-identical, and the Python module walk (64 ms of host time per forward against 90 ms of device time)
+        # stops leaving the queue dry at the 18x32 / 9x16 levels: +1.1 % frames/s on one GPU (profiles/r05_bench_pair_replay.txt).
+        # LKGD_NO_REPLAY=1 walks the modules every step.
+        use_replay = fwd is None and self.use_replay
+        if use_replay:
+            tok_buf = torch.empty(cfg * B * F * H * W, 8, dtype=torch.float16, device=dev)
+            t_dev = torch.zeros(cfg * B, dtype=torch.float32, device=dev)
+            enc_r, ids_r = enc.to(torch.float16).contiguous(), ids.to(torch.float32).contiguous()
+            if ctrl is not None:
+                self.controlnet.prepare()
+                self.controlnet._cond_tokens(ctrl, cfg * B, F, H, W)       # once per clip, outside the recorded forward
+            recorded = None
+
+            def forward_static():
+                down = mid = None
+                if ctrl is not None:
+                    down, mid, _ = self.controlnet.forward_tokens(tok_buf, cfg * B, F, H, W, t_dev, enc_r, ids_r, ctrl,
+                                                                  controlnet_cond_scale)
+                return unet.forward_tokens(tok_buf, cfg * B, F, H, W, t_dev, enc_r, ids_r, down, mid)[0]
         timers = _trace.StepTimers() if _trace.STEP_TIMERS else None      # LKGD_STEP_TIMERS=1: device ms per Euler step
         self.last_step_timers = timers
         for i, t in enumerate(sch.timesteps_host):
@@ -283,6 +307,15 @@ class StableVideoDiffusionPipeline:
             if fwd is not None:
                 ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=fwd.tok)
                 noise_tok = fwd.run(t)
+            elif use_replay:
+                ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=tok_buf)
+                t_dev.fill_(float(t))
+                if recorded is not None:
+                    noise_tok = recorded.run(ops.GEMM_EVENTS)
+                else:
+                    with _replay.record() as recorded:
+                        recorded.result = forward_static()
+                    noise_tok = recorded.result
             else:
                 tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)
                 down = mid = None

@@ -486,6 +486,64 @@ def test_hip_graph_replay_equals_eager_loop():
     assert torch.equal(run(4), changed) and not torch.equal(changed, eager)
 
 
+def test_launch_list_replay_equals_module_walk():
+    """`pipe.denoise` records the first Euler step's forward as a flat launch list and replays it for the other steps (round 5:
+    the default on one GPU too).  Same launches, same arguments: the latents are bit-identical to walking the modules every
+    step (`use_replay = False`) - for the stock loop, with the `patch` joint hooks on two clips, and with the ControlNet encoder
+    in the loop; a callback that edits the latents between steps still takes effect"""
+    from lkgd_amd import controlnet as pc
+    from lkgd_amd import patch
+    from lkgd_amd import unet as pu
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+    _, m = _unet(23)
+    g = torch.Generator().manual_seed(9)
+    lat0 = torch.randn(1, 4, 4, 8, 8, generator=g)
+    enc = torch.cat([torch.zeros(1, 1, 1024), torch.randn(1, 1, 1024, generator=g)]).to(DEV)
+    img = torch.cat([torch.zeros(1, 4, 4, 8, 8), 0.18215 * torch.randn(1, 1, 4, 8, 8, generator=g).repeat(1, 4, 1, 1, 1)])
+    img = img.half().to(DEV)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2).to(DEV)
+    pipe = StableVideoDiffusionPipeline(unet=m)
+
+    def both(fn):
+        pipe.use_replay = True
+        a = fn()
+        pipe.use_replay = False
+        b = fn()
+        pipe.use_replay = True
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+        return a
+
+    def run(lat, img_, enc_, ids_, **kw):
+        pipe.scheduler.set_timesteps(4)
+        return pipe.denoise((lat * float(pipe.scheduler.init_noise_sigma)).half().to(DEV), img_, enc_, ids_, 4, **kw)
+    plain = both(lambda: run(lat0, img, enc, ids))
+    # a callback that halves the latents after step 1: the recorded forward reads the latents through its static token buffer
+    cb = lambda p, i, t, kw: {"latents": kw["latents"] * 0.5} if i == 1 else {}      # noqa: E731
+    assert not torch.equal(both(lambda: run(lat0, img, enc, ids, callback_on_step_end=cb)), plain)
+    # ControlNet encoder in the loop
+    cfg = pu.UNetConfig(**{k: v for k, v in m.config.__dict__.items() if k in pu.UNetConfig.__dataclass_fields__})
+    cn = pc.ControlNetSDVModel(cfg).half().to(DEV)
+    pu.init_synthetic_weights_(cn, seed=6)
+    pipe.controlnet = cn
+    ctrl = (2.0 * torch.rand(1, 4, 3, 64, 64, generator=g) - 1.0).repeat(2, 1, 1, 1, 1).half().to(DEV)
+    assert not torch.equal(both(lambda: run(lat0, img, enc, ids, controlnet_condition=ctrl, controlnet_cond_scale=0.7)), plain)
+    pipe.controlnet = None
+    # two clips with the joint-attention hooks (spatial + temporal), masks [0, 1, 0, 1]
+    patch.apply_patch(pipe, with_temporal_block=True)
+    patch.initialize_joint_layers(pipe)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if "attn1n" in name or "conv1n" in name:
+                prm.copy_((torch.randn(prm.shape, generator=g) * (0.5 / max(prm.shape[-1], 1) ** 0.5)).to(prm))
+    m.invalidate()
+    patch.set_joint_attention_mask(pipe, [0, 1, 0, 1])
+    lat2 = torch.cat([lat0, 0.9 * lat0.flip(1)])
+    img2 = torch.stack([img[0], img[0], img[1], 0.8 * img[1]])
+    enc2 = torch.stack([enc[0], enc[0], enc[1], 0.8 * enc[1]])
+    both(lambda: run(lat2, img2, enc2, ids[:1].repeat(4, 1)))
+    patch.remove_patch(pipe)
+
+
 class _StandInVAE(torch.nn.Module):
     """the boundary stand-in the golden generator used (tests/golden/make_goldens.py::_FakeVAE): 8x average pool + fixed
     channel mix -> 4 latent channels"""
