@@ -198,3 +198,35 @@ def test_hip_masked_lora_vs_reference_golden(golden):
     lora.merge_lora(m)
     assert not lora.lora_layers(m)
     assert _rel(_call(m, i, DEV), single) < 3e-3          # folded once into fp16 base weights vs folded per variant
+
+
+@pytest.mark.gpu
+def test_masked_lora_and_joint_hooks_on_a_cfg_parallel_rank(golden):
+    """round 5: a CFG-parallel rank runs the batch entries [b0, b0 + 2) of the call's four ([u_x, u_y | c_x, c_y]): the joint
+    masks, the partner maps and the per-entry LoRA plan are cut to the rank's entries (unet._joint_maps, lora.EntryPlan(b0=...)),
+    the cross-attention tables keep all four contexts.  Each half computed that way (no process group needed: one frame shard)
+    must reproduce its two entries of the full four-entry forward, which the reference golden pins"""
+    from lkgd_amd import ops, patch
+    from lkgd_amd.dist import make_plan
+    from lkgd_amd.dist_run import ShardInfo
+    g = golden
+    m = _hip_model(g).half().to(DEV)
+    i = lora_inputs()
+    patch.set_joint_attention(m, True)
+    patch.hack_lora_forward(m)
+    for a, mk in MASKS.items():
+        patch.set_patch_lora_mask(m, a, mk)
+    full = _call(m, i, DEV)                                        # [4, F, 4, h, w]
+    assert _rel(full, g["masked"]) < 1e-2
+    B4, F, _, H, W = i["sample"].shape
+    tok = ops.nchw_to_tokens(i["sample"].half().to(DEV).reshape(B4 * F, 8, H, W).contiguous())
+    rows = 2 * F * H * W
+    t_dev = torch.full((2,), float(i["t"]), dtype=torch.float32, device=DEV)
+    for r in range(2):
+        sh = ShardInfo(make_plan(2, r, F, True), None, entries=2)
+        assert sh.b0 == 2 * r and sh.B_total == 4
+        out_tok, _ = m.forward_tokens(tok[r * rows:(r + 1) * rows].contiguous(), 2, F, H, W, t_dev, i["enc"].half().to(DEV),
+                                      i["ids"][2 * r:2 * r + 2].to(DEV), shard=sh)
+        got = ops.tokens_to_nchw(out_tok, 2 * F, 4, H, W).reshape(2, F, 4, H, W)
+        rel = _rel(got, full[2 * r:2 * r + 2])
+        assert rel < 3e-3, f"CFG half {r}: rel L2 {rel:.3e} against its entries of the full forward"
