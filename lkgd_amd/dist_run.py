@@ -226,6 +226,8 @@ class DistDenoiser:
             ops.cfg_euler_step(noise_full, latents, guidance, cfg, sigma, sigma_next, v_prediction=vpred)
         ops.GEMM_EVENTS = events_all
         sch._step_index = num_inference_steps
+        if recorded is not None:
+            recorded.release()
         return latents
 
 

@@ -334,6 +334,8 @@ class StableVideoDiffusionPipeline:
         sch._step_index = num_inference_steps
         if timers is not None:
             timers.finish()
+        if use_replay and recorded is not None:
+            recorded.release()          # the recorded forward's activations (tens of GB at full size) go back to the allocator
         return latents
 
     def _latents_for_decode(self, latents: torch.Tensor) -> torch.Tensor:

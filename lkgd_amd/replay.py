@@ -76,6 +76,14 @@ class Plan:
         self.result = None
         self.lib = None          # recording stand-in for the ctypes library (set by `record`)
 
+    def release(self) -> None:
+        """drop the launch list and every tensor it keeps alive NOW (the plan and its recording stand-in reference each other,
+        so without this the tens of GB of activations a full-size forward's plan holds wait for the cycle collector)"""
+        self.calls.clear()
+        self.keep.clear()
+        self.result = None
+        self.lib = None
+
     def python(self, f: Callable[[], None]) -> None:
         """a host-side step (collective, torch copy) to redo at this point of every replay"""
         self.calls.append((None, f, "py", None))
