@@ -154,6 +154,13 @@ int lkgd_groupnorm_stats_cols(const float* cs0, int32_t blk0, int32_t ldcs0, int
 int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
                          int64_t nsamples, int64_t rows_per_sample, const float* stats, const float* gamma,
                          const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);
+/* lkgd_groupnorm_apply over a table of row segments in ONE launch: segs = nseg x { const void* src; void* dst; int64 rows;
+ * int64 sample; } in DEVICE memory - rows [0, rows) of the [rows, C] matrix at src (row stride ld, as dst) are normalised with
+ * stats[sample] and written to dst; max_rows = the longest segment.  A frame-sharded rank normalises its own frames of every batch
+ * entry and the raw boundary frames it received from its neighbours this way (the same arithmetic as lkgd_groupnorm_apply, bit for
+ * bit). */
+int lkgd_groupnorm_apply_segments(const void* segs, int32_t nseg, int64_t max_rows, int32_t C, int32_t ld, const float* stats,
+                                  const float* gamma, const float* beta, int32_t silu, lkgd_stream_t stream);
 /* the whole F.group_norm (+ F.silu) of a tensor in one call: out = silu?(groupnorm(x)) = lkgd_groupnorm_stats followed by
  * lkgd_groupnorm_apply (the same three launches, the same numbers); `partial` as above, `stats` (nsamples*32*2 floats) receives
  * (mean, rstd). */

@@ -65,6 +65,7 @@ SYMBOLS = {
     "lkgd_groupnorm_sums": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp]),
     "lkgd_groupnorm_finalize": (_i32, [_vp, _i64, C.c_double, _f32, _vp, _vp]),
     "lkgd_groupnorm_finalize_parts": (_i32, [_vp, _i32, _i64, _i64, _i64, C.c_double, _f32, _vp, _vp]),
+    "lkgd_groupnorm_apply_segments": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "lkgd_groupnorm_silu": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "lkgd_groupnorm_apply": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32,
                                     _vp]),

@@ -381,6 +381,67 @@ extern "C" int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, con
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 
+// GroupNorm apply over a TABLE of row segments (frame-sharded ranks): segment s = rows [0, seg[s].rows) of a [rows, C] matrix at
+// seg[s].src, normalised with the statistics of sample seg[s].sample, written to seg[s].dst.  One launch normalises a rank's own
+// frames of every batch entry into the middle of its [F + 2]-frame buffers AND the raw boundary frames it received from its two
+// neighbours into the end slots (lkgd_amd/unet.py::_temporal_norm), instead of three launches per entry.
+struct gn_segment { const half_t* src; half_t* dst; long long rows; long long sample; };
+__global__ __launch_bounds__(256) void gn_apply_segments_kernel(const gn_segment* segs, int C, int ld, const float* stats,
+                                                                const float* gamma, const float* beta, int silu, int GN_ROWS) {
+  const gn_segment sg = segs[blockIdx.y];
+  const long long r0 = (long long)blockIdx.x * GN_ROWS;
+  if (r0 >= sg.rows) return;
+  long long r1 = r0 + GN_ROWS;
+  if (r1 > sg.rows) r1 = sg.rows;
+  const GnMap mp = gn_map(C);
+  const int t = threadIdx.x;
+  const int gs = C / GN_GROUPS;
+  for (int slot = 0; slot < mp.nslot; ++slot) {
+    int cv, rp;
+    if (mp.nslot == 1) { rp = t / mp.C8; cv = t - rp * mp.C8; if (rp >= mp.rows_par) continue; }
+    else { rp = 0; cv = t + 256 * slot; if (cv >= mp.C8) continue; }
+    float A[8], B[8];
+    {
+      const float4_t g0 = *(const float4_t*)(gamma + cv * 8), g1 = *(const float4_t*)(gamma + cv * 8 + 4);
+      const float4_t b0 = *(const float4_t*)(beta + cv * 8), b1 = *(const float4_t*)(beta + cv * 8 + 4);
+      typedef float float2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (cv * 8 + e) / gs;
+        const float2_t mr = *(const float2_t*)(stats + (sg.sample * GN_GROUPS + g) * 2);
+        const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+        A[e] = mr[1] * ga;
+        B[e] = be - mr[0] * A[e];
+      }
+    }
+#pragma unroll 4
+    for (long long r = r0 + rp; r < r1; r += mp.rows_par) {
+      const half8_t v = *(const half8_t*)(sg.src + r * ld + cv * 8);
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[e] * A[e] + B[e];       // the arithmetic of gn_apply_kernel: a row normalised here or there has the same bits
+        if (silu) f = silu_f(f);
+        o[e] = (half_t)f;
+      }
+      *(half8_t*)(sg.dst + r * ld + cv * 8) = o;
+    }
+  }
+}
+
+extern "C" int lkgd_groupnorm_apply_segments(const void* segs, int32_t nseg, int64_t max_rows, int32_t C, int32_t ld,
+                                             const float* stats, const float* gamma, const float* beta, int32_t silu,
+                                             lkgd_stream_t stream) {
+  if (!segs || !stats || !gamma || !beta) return LKGD_E_NULL;
+  if (nseg <= 0 || nseg > 65535 || max_rows <= 0 || C <= 0 || C % GN_GROUPS || C % 8 || C > GN_MAXC || ld % 8 || ld < C) return LKGD_E_SHAPE;
+  if (((uintptr_t)segs & 7u) != 0) return LKGD_E_ALIGN;
+  const int ra = gn_rows(C, max_rows, nseg);
+  const int nchunks = (int)((max_rows + ra - 1) / ra);
+  hipLaunchKernelGGL(gn_apply_segments_kernel, dim3(nchunks, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream,
+                     (const gn_segment*)segs, C, ld, stats, gamma, beta, silu, ra);
+  return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+}
+
 // The whole GroupNorm (+ SiLU) of a tensor in one C call: statistics pass, finalize, apply pass (three launches; what a
 // caller saves is two trips through its own call layer)
 extern "C" int lkgd_groupnorm_silu(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,

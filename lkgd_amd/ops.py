@@ -260,6 +260,24 @@ def groupnorm_apply(x0: torch.Tensor, x1: Optional[torch.Tensor], nsamples: int,
     return out
 
 
+def groupnorm_apply_segments(segments, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, silu: bool = True) -> None:
+    """GroupNorm apply (+ SiLU) over a list of row segments in ONE launch: ``segments`` = [(src [rows, C], dst [rows, C], sample)],
+    each normalised with ``stats[sample]``; src / dst are row-contiguous fp16 views of equal row stride (lkgd_hip.h section 2)"""
+    src0 = segments[0][0]
+    C_, ld = src0.shape[1], _ld(src0)
+    tab = []
+    for src, dst, sample in segments:
+        _req(src, torch.float16, "segment src"); _req(dst, torch.float16, "segment dst")
+        if src.shape != dst.shape or src.shape[1] != C_ or _ld(src) != ld or _ld(dst) != ld:
+            raise _lib.LkgdHipError("groupnorm_apply_segments: segments must be [rows, C] views of one row stride")
+        tab += [src.data_ptr(), dst.data_ptr(), src.shape[0], int(sample)]
+    table = torch.tensor(tab, dtype=torch.int64).to(src0.device)        # (kept alive by the caller's recording, if any)
+    check(_L().lkgd_groupnorm_apply_segments(table.data_ptr(), len(segments), max(s[0].shape[0] for s in segments), C_, ld,
+                                             stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, _stream()),
+          "lkgd_groupnorm_apply_segments")
+    return table
+
+
 def groupnorm_silu(x0, x1, nsamples, rows_per_sample, gamma, beta, eps, silu=True, out=None):
     C_ = x0.shape[1] + (x1.shape[1] if x1 is not None else 0)
     if out is None:

@@ -884,18 +884,18 @@ class SpatioTemporalResBlock(nn.Module):
             n, W = HW * Cc, 2 * HW * Cc + _dist.SUMS_SLOT
             parts = got.view(-1)[2 * n:].view(torch.float32)              # rank 0 / entry 0's sums; strides in floats below
             stats = ops.groupnorm_finalize_parts(parts, k, ctx.B * W // 2, ctx.B, W // 2, count, eps)
+            segs = []             # one launch: own frames of every entry + the neighbours' raw boundary frames
             for b in range(ctx.B):
-                st = stats[b:b + 1]
-                ops.groupnorm_apply(x[b * rows:(b + 1) * rows], None, 1, rows, st, *affine, True, buf[b * blk + HW:(b + 1) * blk - HW])
+                segs.append((x[b * rows:(b + 1) * rows], buf[b * blk + HW:(b + 1) * blk - HW], b))
                 if si == 0:
                     buf[b * blk:b * blk + HW].zero_()
                 else:             # the previous shard's LAST frame
-                    ops.groupnorm_apply(got[si - 1, b, n:2 * n].view(HW, Cc), None, 1, HW, st, *affine, True, buf[b * blk:b * blk + HW])
+                    segs.append((got[si - 1, b, n:2 * n].view(HW, Cc), buf[b * blk:b * blk + HW], b))
                 if si == k - 1:
                     buf[(b + 1) * blk - HW:(b + 1) * blk].zero_()
                 else:             # the next shard's FIRST frame
-                    ops.groupnorm_apply(got[si + 1, b, :n].view(HW, Cc), None, 1, HW, st, *affine, True,
-                                        buf[(b + 1) * blk - HW:(b + 1) * blk])
+                    segs.append((got[si + 1, b, :n].view(HW, Cc), buf[(b + 1) * blk - HW:(b + 1) * blk], b))
+            ops.groupnorm_apply_segments(segs, stats, *affine, True)
             return buf
         sums = ctx.shard.allreduce(ops.groupnorm_sums(x, None, ctx.B, rows))
         stats = ops.groupnorm_finalize(sums, count, eps)

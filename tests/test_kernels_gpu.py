@@ -286,6 +286,31 @@ def test_groupnorm_one_call_equals_three_launches_bitwise(C0, C1, rows, ns):
     _close(one[sub], ref.permute(0, 2, 1).reshape(ns * rows, C)[sub], what="one-call groupnorm")
 
 
+def test_groupnorm_apply_segments_equals_apply_bitwise():
+    """one launch over a table of row segments (a frame-sharded rank: own frames of two entries + four boundary frames of other
+    sizes) = lkgd_groupnorm_apply segment by segment, bit for bit"""
+    from lkgd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for C, HW, F in ((1280, 144, 3), (320, 2304, 2), (640, 100, 4)):
+        x = _h(torch.randn(2 * F * HW, C, generator=g) * 1.5 + 0.2).to(DEV)
+        halo = _h(torch.randn(4 * HW, C, generator=g)).to(DEV)
+        gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+        stats = ops.groupnorm_stats(x, None, 2, F * HW, 1e-5)
+        out = torch.zeros(2 * (F + 2) * HW, C, dtype=torch.float16, device=DEV)
+        want = torch.zeros_like(out)
+        segs = []
+        for b in range(2):
+            blk = (F + 2) * HW
+            trio = [(x[b * F * HW:(b + 1) * F * HW], slice(b * blk + HW, (b + 1) * blk - HW)),
+                    (halo[2 * b * HW:(2 * b + 1) * HW], slice(b * blk, b * blk + HW)),
+                    (halo[(2 * b + 1) * HW:(2 * b + 2) * HW], slice((b + 1) * blk - HW, (b + 1) * blk))]
+            for src, dst in trio:
+                segs.append((src, out[dst], b))
+                ops.groupnorm_apply(src, None, 1, src.shape[0], stats[b:b + 1], gamma, beta, True, want[dst])
+        ops.groupnorm_apply_segments(segs, stats, gamma, beta, True)
+        assert torch.equal(out, want) and out.float().abs().sum().item() > 0
+
+
 def test_layernorm_with_rowbias(ops):
     g = torch.Generator().manual_seed(20)
     for C in (64, 320, 640, 1280):

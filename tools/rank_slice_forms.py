@@ -41,11 +41,24 @@ class LoopbackShard:
         reps = -(-HW // xp.shape[1])
         return xp.repeat(1, reps, 1)[:, :HW].reshape(-1, x.shape[-1]).contiguous()
 
+    entries = 1
+
     def allreduce(self, sums):
         return sums
 
     def halo(self, buf):
         return buf
+
+    def halo_raw(self, first, last, sums):
+        """the one-collective form of round 5 (raw boundary frames + GroupNorm sums in one all-gather): this rank's own row k times"""
+        from lkgd_amd.dist import SUMS_SLOT
+        k, B, n = self.plan.frame_shards, len(first), first[0].numel()
+        send = torch.empty(B, 2 * n + SUMS_SLOT, dtype=first[0].dtype, device=first[0].device)
+        for b in range(B):
+            send[b, :n].copy_(first[b].reshape(-1))
+            send[b, n:2 * n].copy_(last[b].reshape(-1))
+            send[b, 2 * n:].view(torch.float32).copy_((sums[b] / k).reshape(-1))     # k equal parts add up to the local sums
+        return send.unsqueeze(0).repeat(k, 1, 1).contiguous()
 
 
 dev = torch.device("cuda", 0)
@@ -61,14 +74,21 @@ for world in (8, 4, 2):
     line = f"rank of {world} ({frames} frames of one CFG half)"
     for gather in ((False, True) if shard is not None else (False,)):
         ld.TEMPORAL_GATHER = gather
-        for _ in range(2):
-            unet.forward_tokens(tok, 1, frames, h, w, 1.0, (emb if shard is not None else emb1), ids1, shard=shard)
+        from lkgd_amd import replay
+        enc = (emb if shard is not None else emb1).half().contiguous()
+        t_dev = torch.ones(1, dtype=torch.float32, device=dev)
+        unet.forward_tokens(tok, 1, frames, h, w, t_dev, enc, ids1.float().contiguous(), shard=shard)
+        with replay.record() as rec:          # the launch list a rank replays (lkgd_amd/dist_run.py), stand-in exchanges included
+            rec.result = unet.forward_tokens(tok, 1, frames, h, w, t_dev, enc, ids1.float().contiguous(), shard=shard)[0]
+        rec.run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 3
         for _ in range(n):
-            unet.forward_tokens(tok, 1, frames, h, w, 1.0, (emb if shard is not None else emb1), ids1, shard=shard)
+            rec.run()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        line += f" | {'all-gather form' if gather else ('pixel re-sharding' if shard is not None else 'no frame sharding')}: {ms:6.1f} ms"
+        nl = len(rec.calls)
+        rec.release()
+        line += f" | {'all-gather form' if gather else ('pixel re-sharding' if shard is not None else 'no frame sharding')}: {ms:6.1f} ms ({nl} calls)"
     print(line, flush=True)
