@@ -89,6 +89,24 @@ for world in (8, 4, 2):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         nl = len(rec.calls)
+        if os.environ.get("PROFILE") == "1" and not gather:       # per-call device time by entry point (events around every call)
+            from collections import defaultdict
+            stream = torch.cuda.current_stream().cuda_stream
+            evs = []
+            for fn, a, name, flop in rec.calls:
+                if fn is None:
+                    a()
+                    continue
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record(); fn(*a, stream); e_.record()
+                evs.append((name, s_, e_))
+            torch.cuda.synchronize()
+            fam = defaultdict(lambda: [0, 0.0])
+            for name, s_, e_ in evs:
+                fam[name][0] += 1; fam[name][1] += s_.elapsed_time(e_)
+            print(f"  per entry point, world {world}:")
+            for k_, (n_, t_) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+                print(f"    {k_:34s} {n_:4d} calls {t_:7.3f} ms")
         rec.release()
         line += f" | {'all-gather form' if gather else ('pixel re-sharding' if shard is not None else 'no frame sharding')}: {ms:6.1f} ms ({nl} calls)"
     print(line, flush=True)
