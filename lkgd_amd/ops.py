@@ -20,13 +20,32 @@ _zeros = {}
 #: is appended (bench.py's live roofline measurement); None = off
 GEMM_EVENTS = None
 
-#: lkgd_amd.replay.Plan while a kernel sequence is being recorded (every launch below is then also appended to it)
-PLAN = None
+#: lkgd_amd.replay.Plan while THIS host thread records a kernel sequence (every launch below is then also appended to it).
+#: Thread-local: `pipeline.denoise` records by default since round 5, and two threads that drive two pipelines must not write
+#: into each other's launch lists.  Read it as ``ops.PLAN`` (module __getattr__) or ``current_plan()``; set it with ``set_plan``.
+import threading as _threading
+
+_tls = _threading.local()
+
+
+def current_plan():
+    return getattr(_tls, "plan", None)
+
+
+def set_plan(plan) -> None:
+    _tls.plan = plan
+
+
+def __getattr__(name):
+    if name == "PLAN":
+        return current_plan()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def _L():
-    """the C-ABI library, or its recording stand-in while a plan is being recorded"""
-    return PLAN.lib if PLAN is not None else _lib.lib()
+    """the C-ABI library, or its recording stand-in while this thread records a plan"""
+    plan = getattr(_tls, "plan", None)
+    return plan.lib if plan is not None else _lib.lib()
 
 
 def _stream() -> int:
@@ -42,20 +61,22 @@ def zeros_page(device) -> torch.Tensor:
     return z
 
 
-_splitk_ws = {}
 SPLITK_WORKSPACE_BYTES = 256 << 20
 
 
 def splitk_workspace(device) -> torch.Tensor:
     """fp32 scratch for the split-K partial sums of few-row GEMMs; one per device and HOST THREAD: a GEMM and its reduce pass
     are two launches of one C call, stream-ordered against everything this thread enqueues - but a second host thread
-    launching on the same stream could slip its own split GEMM between them (tests/thread_world.py runs ranks as threads)"""
-    import threading
-    key = (device.type, device.index, threading.get_ident())
-    w = _splitk_ws.get(key)
+    launching on the same stream could slip its own split GEMM between them (tests/thread_world.py runs ranks as threads).
+    Kept in thread-local storage: a thread's 256 MB go back to the allocator when the thread ends."""
+    ws = getattr(_tls, "splitk_ws", None)
+    if ws is None:
+        ws = _tls.splitk_ws = {}
+    key = (device.type, device.index)
+    w = ws.get(key)
     if w is None:
         w = torch.empty(SPLITK_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
-        _splitk_ws[key] = w
+        ws[key] = w
     return w
 
 

@@ -123,7 +123,7 @@ class record:
             raise LkgdHipError("nested recording")
         self.plan = Plan()
         self.plan.lib = _RecordingLib(_lib_module.lib(), self.plan)
-        ops.PLAN = self.plan
+        ops.set_plan(self.plan)
         self.mode = _KeepAll(self.plan.keep)
         self.mode.__enter__()
         return self.plan
@@ -131,5 +131,5 @@ class record:
     def __exit__(self, *exc):
         from . import ops
         self.mode.__exit__(*exc)
-        ops.PLAN = None
+        ops.set_plan(None)
         return False

@@ -25,7 +25,8 @@ def test_eight_ranks_cfg_x_4_4_3_3_loop_vs_reference_golden(golden, c1_hip_model
     interior shards per half (halos at both boundaries, all-to-all with uneven rows, padded gathers) - every rank's result
     against the REFERENCE's fp32 run.  Eight GPU processes do not fit this pool's six-process guard, so the ranks run as
     eight THREADS of this process over tests/thread_world.py (a stand-in for the few torch.distributed calls the sharded
-    denoiser makes; same stream, barrier-ordered copies).  Module walk, not replay: the recorder is process-global."""
+    denoiser makes; same stream, barrier-ordered copies).  Every rank replays its recorded launch list from the second Euler
+    step on, as a real rank does (the recorder is thread-local since round 5)."""
     import lkgd_amd.dist as ldist
     import lkgd_amd.dist_run as ldist_run
     from lkgd_amd import unet as pu
@@ -43,7 +44,6 @@ def test_eight_ranks_cfg_x_4_4_3_3_loop_vs_reference_golden(golden, c1_hip_model
         pipe = StableVideoDiffusionPipeline(unet=m)
         pipe.scheduler.set_timesteps(2)
         runner = ldist_run.DistDenoiser(pipe, world, rank, 14, cfg=True)
-        runner.use_replay = False
         assert runner.plan.splits == (4, 4, 3, 3)
         ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
         lat = (golden["latents0"] * float(pipe.scheduler.init_noise_sigma)).half().to(dev)

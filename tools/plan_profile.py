@@ -89,9 +89,18 @@ def family(name, desc):
     return name.replace("lkgd_", "")
 
 
-cases = [int(a) for a in sys.argv[1:]] or [-4, -7]
+cases = [int(a) for a in sys.argv[1:] if a != "full"] or [-4, -7]
 full, wall_full = profile(2, 14)
 print(f"# full forward: {len(full)} calls, sum of per-call times {sum(r[3] for r in full):.2f} ms, replay wall {wall_full:.2f} ms")
+if "full" in sys.argv[1:]:          # the full forward's own table: time and TFLOP/s per GEMM shape, time per other entry point
+    agg = defaultdict(lambda: [0, 0.0, 0.0])
+    for name, desc, flop, t, key in full:
+        a = agg[desc if name == "lkgd_gemm_f16" else name]
+        a[0] += 1; a[1] += t; a[2] += flop
+    print(f"{'call':64s} {'n':>3s} {'ms':>8s} {'us/call':>8s} {'TFLOP/s':>8s}")
+    for k, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{k:64s} {n:3d} {t:8.3f} {t/n*1e3:8.1f} {fl/t/1e9 if fl else 0:8.0f}")
+    cases = [] if sys.argv[1:] == ["full"] else cases
 for c in cases:
     cfgb, fr = (1, -c) if c < 0 else (2, c)
     share = cfgb * fr / 28.0
