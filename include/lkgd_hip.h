@@ -118,6 +118,10 @@ int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream);
 /* rows per `colstats` block of the tile program lkgd_gemm_f16 will run for this descriptor (its colstats field is ignored);
  * 0 = that program does not produce column statistics */
 int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d);
+/* tile columns of the widest tile program for an output of N columns: 320, or 256 where 256 divides N and 320-column tiles would
+ * idle more than a tenth of their columns (N = 256, 512, 768: the temporal VAE decoder's widths, diffusers
+ * AutoencoderKLTemporalDecoder block_out_channels (128, 256, 512, 512)) - introspection for tests and tools */
+int lkgd_gemm_wide_tile_n(int N);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 2. GroupNorm (32 groups) statistics + apply + SiLU on channels-last tokens.

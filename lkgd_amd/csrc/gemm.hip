@@ -460,6 +460,7 @@ static int check_desc(const lkgd_gemm_desc* d) {
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit);   // gemm_wide.hip
+extern "C" int lkgd_gemm_wide_tile_n(int N);     // 320, or 256 for N = 256, 512, 768 ... (the 256x256 form of that program)
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
 extern "C" int lkgd_gemm_resw_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_resw.hip
 extern "C" int lkgd_gemm_resw_ok(const lkgd_gemm_desc* d, int cus);
@@ -576,9 +577,11 @@ static int gemm_pick(const lkgd_gemm_desc* d, int cus, int* wide_ks_out) {   // 
   const bool stream_ok = rows16 && d->geglu != 80;
   // resident-weight kernel: a 160-row slab of W[N][K] in LDS per workgroup, every XCD runs all N / 160 slabs
   const bool rw_ok = lkgd_gemm_resw_ok(d, cus) != 0;
-  const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
-  // N tiles by 320 with at most a fifth of all tile columns idle (N = 256, 512, 768, 1536 ...)
-  const bool n320 = d->N % 320 == 0 || (long long)((d->N + 319) / 320) * 320 * 4 <= (long long)d->N * 5;
+  const int wide_n = lkgd_gemm_wide_tile_n(d->N);
+  const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + wide_n - 1) / wide_n);
+  // N tiles by 320 (by 256 where that divides N and 320 does not: the VAE decoder's 256 / 512) with at most a fifth of all
+  // tile columns idle
+  const bool n320 = d->N % wide_n == 0 || (long long)((d->N + 319) / 320) * 320 * 4 <= (long long)d->N * 5;
   int pick = 0;   // 1 = 128x128, 2 = 256x128 ring, 3 = stream, 4 = wide (256x320), 5 = rowpanel
   int wide_ks = 1;
   if (d->geglu == 80) {
@@ -607,9 +610,9 @@ static int gemm_pick(const lkgd_gemm_desc* d, int cus, int* wide_ks_out) {   // 
                                                          // (the 9x16 level; the 18x32 / 36x64 levels of sharded ranks)
   } else if (wide_ok && d->geglu == 0 && n320 && d->K >= 320 && tiles_wide * 2 >= cus - 16) {
     pick = 4;                                            // every N = 320 / 640 / 960 / 1280 / 1920 / 3840 shape of the model
-                                                         // whose 256x320 tiles fill at least half the CUs; also N = 256 / 512
-                                                         // (the VAE: 20 % of the tile columns idle, still 960-1060 vs 800-860
-                                                         // TFLOP/s on the streaming kernel, tools/micro/vae_shapes_bench.py)
+                                                         // whose 256x320 tiles fill at least half the CUs; N = 256 / 512 (the
+                                                         // VAE decoder) on the 256x256 form of the same program
+                                                         // (tools/micro/vae_shapes_bench.py)
   } else if (d->M < 12288) {
     wide_ks = 1;
     // the 9x16 level (M = 4032; also the 9216-row 36x64 level of a rank of 8): 256-row tilings leave most CUs idle; 128x128
@@ -640,8 +643,9 @@ static int gemm_pick(const lkgd_gemm_desc* d, int cus, int* wide_ks_out) {   // 
 static int gemm_wide_slices(const lkgd_gemm_desc* d, int cus, int pick, int wide_ks) {
   if (pick != 4) return 1;
   if (gemm_variant_override == 4) {
-    const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + 319) / 320);
-    wide_ks = wide_split(d, tiles_wide, cus);
+    const int wide_n = lkgd_gemm_wide_tile_n(d->N);
+    const long long tiles_wide = (long long)((d->M + 255) / 256) * ((d->N + wide_n - 1) / wide_n);
+    wide_ks = wide_n == 320 ? wide_split(d, tiles_wide, cus) : 1;
   }
   return wide_ks >= 2 ? wide_ks : 1;
 }
@@ -654,7 +658,8 @@ extern "C" int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d) {
   const int pick = gemm_pick(d, cus, &wide_ks);
   if (pick == 6) return lkgd_gemm_resw_colstats_ok(d) ? 32 : 0;
   // the 256x320 program sums the columns of the row segments it parks in LDS: whole 320-column tiles, unsliced K
-  if (pick == 4 && gemm_wide_slices(d, cus, pick, wide_ks) == 1 && d->N % 320 == 0 && d->ldc % 8 == 0 && aligned16(d->out))
+  if (pick == 4 && gemm_wide_slices(d, cus, pick, wide_ks) == 1 && d->N % lkgd_gemm_wide_tile_n(d->N) == 0 && d->ldc % 8 == 0 &&
+      aligned16(d->out))
     return 256;
   return 0;
 }

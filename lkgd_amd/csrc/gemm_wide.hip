@@ -81,7 +81,7 @@ struct WideIn {                 // what one K-tile body needs about the NEXT K-t
 
 // statement A: barrier, K-step 0 (fragment reads, the nine DMA loads of the next K-tile, 40 MFMAs) and the reads of K-step 1's
 // first fragments, which leave in x1 / w0
-template <bool FIRST>
+template <bool FIRST, int NF>
 __device__ __forceinline__ void wide_ktile_a(half8_t (&x1)[4], half8_t& w0, int xa0, int xa1, int wa0, int wa1,
                                              const half_t* const (&pA)[4], const WideIn& in, int m_a) {
   half8_t x0, x1_, x2, x3, w1;
@@ -92,7 +92,13 @@ __device__ __forceinline__ void wide_ktile_a(half8_t (&x1)[4], half8_t& w0, int 
                : "v"(xa0), "v"(xa1), "v"(wa0), "v"(wa1), "v"(pA[0]), "v"(pA[1]), "v"(pA[2]), "v"(pA[3]),               \
                  "v"(in.oB[0]), "v"(in.oB[1]), "v"(in.oB[2]), "v"(in.oB[3]), "v"(in.oB[4]), "s"(in.wk), "s"(m_a)       \
                : "memory", "scc", WIDE_AGPR_CLOBBERS)
-  if (FIRST) {
+  if (NF == 8) {              // the 256x256 form: eight weight fragments per wave, four weight loads per thread (in.oB[4] unused)
+    if (FIRST) {
+      WIDE_STMT(WIDE8_KTILE_ASM_FIRST_A);
+    } else {
+      WIDE_STMT(WIDE8_KTILE_ASM_NEXT_A);
+    }
+  } else if (FIRST) {
     WIDE_STMT(WIDE_KTILE_ASM_FIRST_A);
   } else {
     WIDE_STMT(WIDE_KTILE_ASM_NEXT_A);
@@ -102,12 +108,19 @@ __device__ __forceinline__ void wide_ktile_a(half8_t (&x1)[4], half8_t& w0, int 
 
 // statement B: K-step 1 (40 MFMAs).  The C++ between A and B prepares the NEXT K-tile's sources while K-step 0's MFMAs drain
 // (between two K-tiles it would sit behind the barrier with the matrix pipe idle).
+template <int NF>
 __device__ __forceinline__ void wide_ktile_b(const half8_t (&x1)[4], half8_t w0, int wa1) {
   half8_t w1;
-  asm volatile(WIDE_KTILE_ASM_B
-               : "=&v"(w1), "+v"(w0)
-               : "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]), "v"(wa1)
-               : "memory", WIDE_AGPR_CLOBBERS);
+  if (NF == 8)
+    asm volatile(WIDE8_KTILE_ASM_B
+                 : "=&v"(w1), "+v"(w0)
+                 : "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]), "v"(wa1)
+                 : "memory", WIDE_AGPR_CLOBBERS);
+  else
+    asm volatile(WIDE_KTILE_ASM_B
+                 : "=&v"(w1), "+v"(w0)
+                 : "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]), "v"(wa1)
+                 : "memory", WIDE_AGPR_CLOBBERS);
 }
 
 // accumulator fragment (weight fragment i, token fragment j) out of the AGPRs; BASE = (4i + j) * 4
@@ -126,14 +139,27 @@ template <class F, int... Is> __device__ __forceinline__ void wide_static_for(F&
 template <class F> __device__ __forceinline__ void wide_for10(F&& f) {
   wide_static_for(f, WideIC<0>{}, WideIC<1>{}, WideIC<2>{}, WideIC<3>{}, WideIC<4>{}, WideIC<5>{}, WideIC<6>{}, WideIC<7>{}, WideIC<8>{}, WideIC<9>{});
 }
+template <class F> __device__ __forceinline__ void wide_for8(F&& f) {
+  wide_static_for(f, WideIC<0>{}, WideIC<1>{}, WideIC<2>{}, WideIC<3>{}, WideIC<4>{}, WideIC<5>{}, WideIC<6>{}, WideIC<7>{});
+}
+template <int NF, class F> __device__ __forceinline__ void wide_for_nf(F&& f) {     // over a wave's weight fragments
+  if constexpr (NF == 8) wide_for8(f);
+  else wide_for10(f);
+}
 template <class F> __device__ __forceinline__ void wide_for5(F&& f) {
   wide_static_for(f, WideIC<0>{}, WideIC<1>{}, WideIC<2>{}, WideIC<3>{}, WideIC<4>{});
 }
 
 // SPLIT = false is the production instantiation: ksplit folds to 1 and the slice bookkeeping disappears (with it in, the
 // allocator spilled 19-34 instead of 2-20 registers around the K-loop and every launch of this kernel got ~2 % slower)
-template <int MODE, bool SPLIT, bool LDSOUT>
+// NF = weight fragments per wave: 10 = the 256x320 tile (wave tile 64 x 160), 8 = the 256x256 tile (64 x 128) for channel
+// counts that are multiples of 256 and not of 320 (the VAE decoder's 256 / 512).  The LDS map is the 256x320 one in both
+// forms (the weight part of a stage is filled to 32 of its 40 KiB), so is everything outside the constants below.
+template <int MODE, bool SPLIT, bool LDSOUT, int NF>
 __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, int tiles_n, int ksplit_arg, float* ws) {
+  static_assert(NF == 10 || (NF == 8 && !SPLIT), "wave tiles: 64 x 160 or 64 x 128 (the latter unsliced)");
+  constexpr int WN = 32 * NF;       // tile columns
+  constexpr int WCH = 16 * NF;      // a wave's channels
   const int ksplit = SPLIT ? ksplit_arg : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -200,8 +226,8 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) ag.rd[i] = lean_row<MODE>(p, WIDE_A_ROW(tm * WBM) + srow + 64 * i, rcp0, rcp1);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-          int n = tn * WBN + srow + 64 * i;
+        for (int i = 0; i < NF / 2; ++i) {
+          int n = tn * WN + srow + 64 * i;
           n = n < p.N ? n : p.N - 1;     // clamped: channels past N are computed on a copy of the last row, never stored
           in.oB[i] = ((unsigned)n * (unsigned)p.K + schunk * 8) * 2u;
         }
@@ -209,8 +235,8 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
         // the tile's bias strip rides the LDS-DMA stream too (4 bytes per lane, waves 0-4): the epilogue then reads it with
         // ds_read_b128 instead of waiting one global-load latency per token fragment
         st_par ^= 1;
-        if (p.bias && w < 5) {
-          int n = tn * WBN + w * 64 + lane;
+        if (p.bias && w < NF / 2) {
+          int n = tn * WN + w * 64 + lane;
           n = n < p.N ? n : p.N - 1;
           __builtin_amdgcn_global_load_lds(GLB_PTR(p.bias + n), LDS_PTR(smem + WBIAS_OFF + st_par * (WBN * 4) + w * 256), 4, 0, 0);
         }
@@ -223,7 +249,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
           const unsigned i0 = ((mf / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (unsigned)p.rb_c0) % (unsigned)p.rb_md;
           const unsigned i1 = ((ml / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (unsigned)p.rb_c0) % (unsigned)p.rb_md;
           int dw = (w - 5) * 64 + lane;
-          int col = tn * WBN + 2 * (dw < 160 ? dw : 159);
+          int col = tn * WN + 2 * (dw < WN / 2 ? dw : WN / 2 - 1);
           col = col < p.N - 2 ? col : p.N - 2;
           char* dst = smem + WRB_OFF + st_par * (2 * WRB_STRIP) + (w - 5) * 256;
           const half_t* rb = (const half_t*)p.rowbias;
@@ -254,7 +280,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
   int xa0, xa1, wa0, wa1;       // LDS addresses of fragment 0 (tokens / weights, K-step 0 / 1) in the CURRENT stage
   {
     const int x_base = (wr * 64 + l15) * 128;
-    const int w_base = WBM * BK * 2 + (wc * 160 + l15) * 128;
+    const int w_base = WBM * BK * 2 + (wc * WCH + l15) * 128;
     const int ch0 = ((0 + lq) ^ skey) << 4, ch1 = ((4 + lq) ^ skey) << 4;
     xa0 = x_base + ch0; xa1 = x_base + ch1; wa0 = w_base + ch0; wa1 = w_base + ch1;
   }
@@ -266,7 +292,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(ag.aptr[i], sx + 8192 * i);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) glds16((const half_t*)((const char*)in.wk + in.oB[i]), sx + WBM * BK * 2 + 8192 * i);
+    for (int i = 0; i < NF / 2; ++i) glds16((const half_t*)((const char*)in.wk + in.oB[i]), sx + WBM * BK * 2 + 8192 * i);
   }
   next_in(in);                  // K-tile 1
 
@@ -297,11 +323,11 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
 #endif
     const int m_a = (cur ^ 1) * WSTAGE_BYTES + w * 1024;
     half8_t x1[4], w0;
-    if (kt == 0) wide_ktile_a<true>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
-    else wide_ktile_a<false>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    if (kt == 0) wide_ktile_a<true, NF>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    else wide_ktile_a<false, NF>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
     const int wa1_now = wa1;
     next_in(in);                // K-tile s+2's sources, for the next body
-    wide_ktile_b(x1, w0, wa1_now);
+    wide_ktile_b<NF>(x1, w0, wa1_now);
     {
       const int d = cur ? -WSTAGE_BYTES : WSTAGE_BYTES;      // the other stage becomes the current one
       xa0 += d; xa1 += d; wa0 += d; wa1 += d;
@@ -325,15 +351,15 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
       const int slice = tile % ksplit;
       tile += nc;
       const int m0 = tm * WBM + wr * 64 + l15;
-      const int n0 = tn * WBN + wc * 160 + 4 * lq;
+      const int n0 = tn * WN + wc * WCH + 4 * lq;
       const half_t* rbp = (const half_t*)p.rowbias;
       const half_t* r1p = (const half_t*)p.res1;
       const half_t* r2p = (const half_t*)p.res2;
       half_t* outp = (half_t*)p.out;
       // one token fragment (16 tokens x 160 channels) at a time
       ep_par ^= 1;
-      const float* bl = (const float*)(smem + WBIAS_OFF + ep_par * (WBN * 4)) + wc * 160 + 4 * lq;   // bias[n0 + ...]
-      const half_t* rbl = (const half_t*)(smem + WRB_OFF + ep_par * (2 * WRB_STRIP)) + wc * 160 + 4 * lq;
+      const float* bl = (const float*)(smem + WBIAS_OFF + ep_par * (WBN * 4)) + wc * WCH + 4 * lq;   // bias[n0 + ...]
+      const half_t* rbl = (const half_t*)(smem + WRB_OFF + ep_par * (2 * WRB_STRIP)) + wc * WCH + 4 * lq;
       // rows below rb_bound use the first strip, the others the second (the map changes at most once inside the tile)
       const unsigned rb_bound = rb_lds ? ((unsigned)(tm * WBM) / (unsigned)p.rb_d1 + 1u) * (unsigned)p.rb_d1 : 0u;
       // Output rows through LDS (LDSOUT: the plain linears without GEGLU).  In the accumulator layout a lane holds 4 channels
@@ -362,20 +388,20 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
         if (!lds_out && !live) return;
         if (SPLIT) {                 // fp32 partial tile of this K slice; bias / residuals / rounding happen in the reduce pass
           float* dst = ws + ((long long)slice * p.M + m) * p.N;
-          wide_for10([&](auto ic) {
+          wide_for_nf<NF>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const float4_t ev = wide_read_acc<(4 * i + j) * 4>();
             if (n0 + i * 16 < p.N) *(float4_t*)(dst + n0 + i * 16) = ev;
           });
           return;
         }
-        const bool gg = MODE == LKGD_A_PLAIN && !lds_out && p.geglu;      // (the launcher never pairs GEGLU with LDSOUT)
+        const bool gg = NF == 10 && MODE == LKGD_A_PLAIN && !lds_out && p.geglu;      // (the launcher never pairs GEGLU with LDSOUT, nor with NF = 8)
         if (!gg) {
           unsigned idx = 0;          // 32-bit row-map arithmetic: M < 2^24 is a launch condition of this kernel
           if (rbp && !rb_lds && live) idx = (((unsigned)m / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + ((unsigned)m % (unsigned)p.rb_d2) +
                                              (unsigned)p.rb_c0) % (unsigned)p.rb_md;
           const int rb_sel = (unsigned)m < rb_bound ? 0 : WRB_STRIP / 2;
-          wide_for10([&](auto ic) {
+          wide_for_nf<NF>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int n = n0 + i * 16;
             float4_t v = wide_read_acc<(4 * i + j) * 4>();
@@ -429,9 +455,9 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
         }
         if (lds_out) {
           // the fragment's rows as 16-byte pieces: piece c of the wave's 16 x (20 | 10) grid -> row c / per, column piece c % per
-          const int per = gg ? 10 : 20;                               // 16-byte pieces per row (80 | 160 channels)
+          const int per = gg ? 10 : 2 * NF;                           // 16-byte pieces per row (80 | 160 | 128 channels)
           const long long mrow0 = (long long)tm * WBM + wr * 64 + j * 16;
-          if (cs_on && lane_e < 40) {
+          if (cs_on && lane_e < 4 * NF) {
             // branch-free over the 16 rows (rows past M are weighted 0): the reads issue back to back; per channel PAIR
             // one v_dot2_f32_f16 for the sum and one for the sum of squares (fp16 products are exact in fp32)
             const long long left = (long long)p.M - mrow0;
@@ -453,12 +479,12 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
               }
             }
           }
-          const int ncol0 = gg ? tn * 160 + wc * 80 : tn * WBN + wc * 160;
+          const int ncol0 = gg ? tn * 160 + wc * 80 : tn * WN + wc * WCH;
 #pragma unroll
           for (int kk = 0; kk < 5; ++kk) {
             const int c = lane_e + 64 * kk;
             if (c < 16 * per) {
-              const int row = gg ? (c * 205) >> 11 : (c * 205) >> 12;   // c / 10, c / 20 for c < 320
+              const int row = NF == 8 ? c >> 4 : (gg ? (c * 205) >> 11 : (c * 205) >> 12);   // c / 16 | c / 10, c / 20 for c < 320
               const int cc = c - row * per;
               const half8_t v = *(const half8_t*)(scr + row * WIDE_OUT_PITCH + cc * 16);
               const long long mr = mrow0 + row;
@@ -478,15 +504,15 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
         // [row group wr][160 channel pairs][sum, sum of squares] behind the eight waves' row patches in the free stage; the
         // next K-tile body starts with a barrier before anything is loaded into this stage
         float* part = (float*)(smem + (cur ^ 1) * WSTAGE_BYTES + 8 * 16 * WIDE_OUT_PITCH);
-        if (lane_e < 40)
-          *(float4_t*)(part + (wr * (WBN / 2) + wc * 80 + 2 * lane_e) * 2) = (float4_t){csum[0], csq[0], csum[1], csq[1]};
+        if (lane_e < 4 * NF)
+          *(float4_t*)(part + (wr * (WN / 2) + wc * (WCH / 2) + 2 * lane_e) * 2) = (float4_t){csum[0], csq[0], csum[1], csq[1]};
         __builtin_amdgcn_s_barrier();
-        if (t < WBN / 2) {
+        if (t < WN / 2) {
           float a = 0.f, b = 0.f;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) { a += part[(g * (WBN / 2) + t) * 2]; b += part[(g * (WBN / 2) + t) * 2 + 1]; }
+          for (int g = 0; g < 4; ++g) { a += part[(g * (WN / 2) + t) * 2]; b += part[(g * (WN / 2) + t) * 2 + 1]; }
           typedef float float2v __attribute__((ext_vector_type(2)));
-          *(float2v*)(p.colstats + ((long long)tm * (p.N / 2) + tn * (WBN / 2) + t) * 2) = (float2v){a, b};
+          *(float2v*)(p.colstats + ((long long)tm * (p.N / 2) + tn * (WN / 2) + t) * 2) = (float2v){a, b};
         }
       }
 #ifdef WIDE_X_STAMPS
@@ -503,59 +529,69 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
 #endif
 }
 
-template <int MODE, bool LDSOUT>
+template <int MODE, bool LDSOUT, int NF = 10>
 __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n) {
-  wide_body<MODE, false, LDSOUT>(p, tiles_m, tiles_n, 1, nullptr);
+  wide_body<MODE, false, LDSOUT, NF>(p, tiles_m, tiles_n, 1, nullptr);
 }
 template <int MODE>
 __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_split_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit, float* ws) {
-  wide_body<MODE, true, false>(p, tiles_m, tiles_n, ksplit, ws);
+  wide_body<MODE, true, false, 10>(p, tiles_m, tiles_n, ksplit, ws);
 }
 
 // ksplit > 1: K is cut into ksplit equal slices (ksplit divides K / 64); the caller runs lkgd_gemm_splitk_reduce afterwards
 static int wide_lds_out_override = -1;     // A/B knob: 0 = direct 8-byte stores everywhere, 1 / -1 = rows through LDS where used
 extern "C" void lkgd_debug_set_wide_lds_out(int on) { wide_lds_out_override = on; }
 
+// the 256x256 form serves channel counts that are whole 256-column tiles and not whole 320-column ones (256, 512, 768 ...)
+// and would leave more than a tenth of the 320-wide tile columns idle (3072 = 9.6 x 320 stays on 320)
+extern "C" int lkgd_gemm_wide_tile_n(int N) {
+  return (N % WBN != 0 && N % 256 == 0 && (long long)((N + WBN - 1) / WBN) * WBN * 10 > (long long)N * 11) ? 256 : WBN;
+}
+
 extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
+#define WIDE_FN(...) (const void*)lkgd_gemm_wide_kernel<__VA_ARGS__>
   LKGD_DEVICE_ONCE_BEGIN
-    const void* fns[9] = {(const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, false>,
-                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, false>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>,
-                          (const void*)lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, true>, (const void*)lkgd_gemm_wide_kernel<LKGD_A_TCONV3, true>,
-                          (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>,
-                          (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>};
+    const void* fns[] = {WIDE_FN(LKGD_A_PLAIN, false), WIDE_FN(LKGD_A_CONV3X3, false), WIDE_FN(LKGD_A_TCONV3, false),
+                         WIDE_FN(LKGD_A_PLAIN, true), WIDE_FN(LKGD_A_CONV3X3, true), WIDE_FN(LKGD_A_TCONV3, true),
+                         (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>,
+                         (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>,
+                         WIDE_FN(LKGD_A_PLAIN, false, 8), WIDE_FN(LKGD_A_CONV3X3, false, 8), WIDE_FN(LKGD_A_TCONV3, false, 8),
+                         WIDE_FN(LKGD_A_PLAIN, true, 8), WIDE_FN(LKGD_A_CONV3X3, true, 8), WIDE_FN(LKGD_A_TCONV3, true, 8)};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) != hipSuccess) return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
-  int tiles_m = (d->M + WBM - 1) / WBM, tiles_n = (d->N + WBN - 1) / WBN;
+#undef WIDE_FN
+  const int wn = lkgd_gemm_wide_tile_n(d->N);
+  int tiles_m = (d->M + WBM - 1) / WBM, tiles_n = (d->N + wn - 1) / wn;
   if (ksplit < 1 || (d->K / BK) % ksplit || (ksplit > 1 && (!d->workspace || d->geglu))) return LKGD_E_SHAPE;
+  if (wn == 256 && (ksplit > 1 || d->geglu)) return LKGD_E_SHAPE;       // K slices and the GEGLU interleave exist for 320-column tiles only
   long long ntiles = (long long)tiles_m * tiles_n * ksplit;
   if (ntiles > 0x7fffffffLL) return LKGD_E_SHAPE;
   int grid = ntiles < cus ? (int)ntiles : cus;
   if (d->M >= (1 << 24)) return LKGD_E_SHAPE;            // float-reciprocal row decomposition (gemm_common.h)
   float* ws = (float*)d->workspace;
-  // plain linears without GEGLU, whole 320-column tiles, 16-byte aligned output rows: the rows leave through LDS (see the epilogue)
+  // plain linears without GEGLU, whole tile columns, 16-byte aligned output rows: the rows leave through LDS (see the epilogue)
   // (the convolutions only when column statistics are asked for: they are summed from the rows in LDS)
-  const bool lds_ok = ksplit == 1 && !d->geglu && d->N % WBN == 0 && d->ldc % 8 == 0 && aligned16(d->out);
+  const bool lds_ok = ksplit == 1 && !d->geglu && d->N % wn == 0 && d->ldc % 8 == 0 && aligned16(d->out);
   if (d->colstats && !lds_ok) return LKGD_E_SHAPE;
   const bool lds_out = lds_ok && (d->colstats ? true : (wide_lds_out_override != 0 && d->mode == LKGD_A_PLAIN));
+#define WIDE_GO(...) \
+  hipLaunchKernelGGL((lkgd_gemm_wide_kernel<__VA_ARGS__>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n)
 #define WIDE_LAUNCH(MODE_)                                                                                              \
   {                                                                                                                     \
     if (ksplit > 1)                                                                                                     \
       hipLaunchKernelGGL(lkgd_gemm_wide_split_kernel<MODE_>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws); \
-    else                                                                                                                \
-      hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE_, false>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n); \
+    else if (wn == 256) {                                                                                               \
+      if (lds_out) WIDE_GO(MODE_, true, 8); else WIDE_GO(MODE_, false, 8);                                              \
+    } else {                                                                                                            \
+      if (lds_out) WIDE_GO(MODE_, true, 10); else WIDE_GO(MODE_, false, 10);                                            \
+    }                                                                                                                   \
   }
-  if (lds_out && d->mode == LKGD_A_PLAIN)
-    hipLaunchKernelGGL((lkgd_gemm_wide_kernel<LKGD_A_PLAIN, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
-  else if (lds_out && d->mode == LKGD_A_CONV3X3)
-    hipLaunchKernelGGL((lkgd_gemm_wide_kernel<LKGD_A_CONV3X3, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
-  else if (lds_out && d->mode == LKGD_A_TCONV3)
-    hipLaunchKernelGGL((lkgd_gemm_wide_kernel<LKGD_A_TCONV3, true>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n);
-  else
   if (d->mode == LKGD_A_PLAIN) WIDE_LAUNCH(LKGD_A_PLAIN)
   else if (d->mode == LKGD_A_CONV3X3) WIDE_LAUNCH(LKGD_A_CONV3X3)
   else if (d->mode == LKGD_A_TCONV3) WIDE_LAUNCH(LKGD_A_TCONV3)
 #undef WIDE_LAUNCH
+#undef WIDE_GO
   else
     return LKGD_E_MODE;
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;

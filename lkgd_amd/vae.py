@@ -90,11 +90,15 @@ class ResnetBlock2D(nn.Module):
         if self.conv_shortcut is not None:
             self._ws, self._bs = pack_linear(self.conv_shortcut.weight.detach()), _f32(self.conv_shortcut.bias)
 
-    def run(self, x, N, H, W):
+    def run(self, x, N, H, W, next_rows=None):
+        """``next_rows``: rows per sample of the GroupNorm that reads this block's output (default H*W: a spatial norm; the
+        temporal res block's norm spans F*H*W) - the convolutions leave that norm's column sums where their tile program
+        has them (ops.gemm ``colstats``: the 256 / 512-channel levels), and its separate read pass disappears"""
         T, geo = N * H * W, (H, W, H, W, 1, 0)
         n1 = _gn(x, N, H * W, self.norm1)
         h = _new(T, self.cout, x.device)
-        ops.gemm(n1, self._w1, h, M=T, N=self.cout, K=9 * self.cin, bias=self._b1, mode=ops.A_CONV3X3, Cin=self.cin, conv=geo)
+        ops.gemm(n1, self._w1, h, M=T, N=self.cout, K=9 * self.cin, bias=self._b1, mode=ops.A_CONV3X3, Cin=self.cin, conv=geo,
+                 colstats=H * W)
         n2 = _gn(h, N, H * W, self.norm2)
         sc = x
         if self.conv_shortcut is not None:
@@ -102,7 +106,7 @@ class ResnetBlock2D(nn.Module):
             ops.gemm(x, self._ws, sc, M=T, N=self.cout, K=self.cin, bias=self._bs)
         out = _new(T, self.cout, x.device)
         ops.gemm(n2, self._w2, out, M=T, N=self.cout, K=9 * self.cout, bias=self._b2, mode=ops.A_CONV3X3, Cin=self.cout,
-                 conv=geo, res1=sc)
+                 conv=geo, res1=sc, colstats=next_rows or H * W)
         return out
 
 
@@ -143,15 +147,15 @@ class SpatioTemporalResBlock(nn.Module):
         self._wt = float(torch.sigmoid(self.time_mixer.mix_factor.detach().float()).item())
 
     def run(self, x, B, F, H, W):
-        s = self.spatial_res_block.run(x, B * F, H, W)
+        s = self.spatial_res_block.run(x, B * F, H, W, next_rows=F * H * W)
         t, c, HW, T = self.temporal_res_block, self.temporal_res_block.c, H * W, B * F * H * W
         n3 = _gn(s, B, F * HW, t.norm1)                      # statistics span the frames of the chunk
         h = _new(T, c, x.device)
-        ops.gemm(n3, t._w1, h, M=T, N=c, K=3 * c, bias=t._b1, mode=ops.A_TCONV3, Cin=c, tconv=(F, HW))
+        ops.gemm(n3, t._w1, h, M=T, N=c, K=3 * c, bias=t._b1, mode=ops.A_TCONV3, Cin=c, tconv=(F, HW), colstats=F * HW)
         n4 = _gn(h, B, F * HW, t.norm2)
         out = _new(T, c, x.device)
         ops.gemm(n4, t._w2, out, M=T, N=c, K=3 * c, bias=t._b2, mode=ops.A_TCONV3, Cin=c, tconv=(F, HW), s_acc=self._wt,
-                 res1=s)
+                 res1=s, colstats=HW)              # -> the next block's spatial norm1 / conv_norm_out
         return out
 
 
@@ -235,7 +239,7 @@ class Upsample2D(nn.Module):
         Ho, Wo = 2 * H, 2 * W
         out = _new(N * Ho * Wo, self.c, x.device)
         ops.gemm(x, self._w, out, M=N * Ho * Wo, N=self.c, K=9 * self.c, bias=self._b, mode=ops.A_CONV3X3, Cin=self.c,
-                 conv=(Ho, Wo, H, W, 1, 1))                       # nearest-2x folded into the gather
+                 conv=(Ho, Wo, H, W, 1, 1), colstats=Ho * Wo)     # nearest-2x folded into the gather
         return out, Ho, Wo
 
 

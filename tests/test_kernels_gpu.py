@@ -700,6 +700,85 @@ def test_gemm_wide_rows_through_lds_match_direct_stores():
         L.lkgd_debug_set_wide_lds_out(-1)
 
 
+def test_gemm_wide_256_column_tiles():
+    """the 256x256 form of the 256x320 program (wave tile 64 x 128: channel counts 256 / 512 / 768 - the VAE decoder's
+    widths): plain linear with bias + residual + both row-bias paths on ragged M and a column-slice output, 3x3 conv
+    (stride 1, upsampled input), temporal conv; both output paths bit-identical; the GroupNorm sums of its epilogue"""
+    from lkgd_amd import _lib, ops
+    from lkgd_amd.packing import pack_conv3x3, pack_tconv3
+    L = _lib.lib()
+    assert L.lkgd_gemm_wide_tile_n(256) == 256 and L.lkgd_gemm_wide_tile_n(512) == 256 and L.lkgd_gemm_wide_tile_n(768) == 256
+    assert L.lkgd_gemm_wide_tile_n(640) == 320 and L.lkgd_gemm_wide_tile_n(3072) == 320 and L.lkgd_gemm_wide_tile_n(128) == 320
+    g = torch.Generator().manual_seed(256)
+
+    def both(fn, shape, cols=None):
+        outs = []
+        for on in (0, 1):
+            L.lkgd_debug_set_wide_lds_out(on)
+            buf = torch.full(shape, -7.0, dtype=torch.float16, device=DEV)
+            fn(buf if cols is None else buf[:, cols[0]:cols[1]])
+            outs.append(buf.cpu())
+        L.lkgd_debug_set_wide_lds_out(-1)
+        assert torch.equal(outs[0], outs[1])
+        return outs[1]
+
+    L.lkgd_debug_set_gemm_variant(4)
+    try:
+        for M, N, K, d1 in ((256 * 5 + 77, 512, 320, 300), (256 * 9, 256, 1024, 40), (700, 768, 128, 256)):
+            a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
+            b = torch.randn(N, generator=g)
+            res = _h(torch.randn(M, N, generator=g))
+            table = _h(torch.randn(5, N, generator=g))
+            idx = (torch.arange(M) // d1) % 5
+            out = both(lambda o: ops.gemm(a.to(DEV), w.to(DEV), o, M=M, N=N, K=K, bias=b.to(DEV), res1=res.to(DEV), r1=0.5,
+                                          rowbias=table.to(DEV), rowmap=(d1, 1, 1, 5, 0)), (M + 3, N + 128), cols=(64, 64 + N))
+            _close(out[:M, 64:64 + N], a.float() @ w.float().T + b + table.float()[idx] + 0.5 * res.float(),
+                   what=f"256-column tiles {M}x{N}x{K}")
+            assert (out[M:] == -7).all() and (out[:, :64] == -7).all() and (out[:, 64 + N:] == -7).all()
+        # 3x3 conv 128 -> 256 on 3 images of 40x24 (ragged last tile) and 64 -> 512 on a 2x-upsampled 20x12 input
+        for Cin, Cout, H, W, ups in ((128, 256, 40, 24, 0), (64, 512, 20, 12, 1)):
+            Nimg = 3
+            x = _h(torch.randn(Nimg, Cin, H, W, generator=g))
+            wc = _h(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5)
+            bc = torch.randn(Cout, generator=g)
+            Ho, Wo = H << ups, W << ups
+            out = both(lambda o: ops.gemm(_tokens(x).to(DEV), pack_conv3x3(wc).to(DEV), o, M=Nimg * Ho * Wo, N=Cout, K=9 * Cin,
+                                          bias=bc.to(DEV), mode=ops.A_CONV3X3, Cin=Cin, conv=(Ho, Wo, H, W, 1, ups)),
+                       (Nimg * Ho * Wo, Cout))
+            xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+            _close(_untokens(out, Nimg, Ho, Wo), F.conv2d(xin, wc.float(), bc, padding=1), what=f"256-column conv {Cin}->{Cout}")
+        Bc, Fr, C, Ht, Wt = 1, 5, 256, 23, 10
+        x5 = _h(torch.randn(Bc, C, Fr, Ht, Wt, generator=g))
+        wt = _h(torch.randn(C, C, 3, 1, 1, generator=g) / (3 * C) ** 0.5)
+        bt = torch.randn(C, generator=g)
+        tok = x5.permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous()
+        out = both(lambda o: ops.gemm(tok.to(DEV), pack_tconv3(wt).to(DEV), o, M=Bc * Fr * Ht * Wt, N=C, K=3 * C, bias=bt.to(DEV),
+                                      mode=ops.A_TCONV3, Cin=C, tconv=(Fr, Ht * Wt)), (Bc * Fr * Ht * Wt, C))
+        reft = F.conv3d(x5.float(), wt.float(), bt, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, C)
+        _close(out, reft, what="256-column tconv")
+        # GroupNorm sums from the epilogue: conv 128 -> 512 on 4 images of 16x32 (two tiles per image), against the read pass
+        Nimg, H, W = 4, 16, 32
+        T = Nimg * H * W
+        x = _h(torch.randn(T, 128, generator=g)).to(DEV)
+        w = torch.randn(512, 128, 3, 3, generator=g) / (9 * 128) ** 0.5
+        out = torch.empty(T, 512, dtype=torch.float16, device=DEV)
+        ops.gemm(x, pack_conv3x3(w).to(DEV), out, M=T, N=512, K=9 * 128, bias=torch.randn(512, generator=g).to(DEV),
+                 mode=ops.A_CONV3X3, Cin=128, conv=(H, W, H, W, 1, 0), colstats=H * W)
+        assert out._lkgd_colstats[1] == 256
+        got = ops.groupnorm_stats(out, None, Nimg, H * W, 1e-6)
+        ops.COLSTATS = False
+        try:
+            two_pass = ops.groupnorm_stats(out, None, Nimg, H * W, 1e-6)
+        finally:
+            ops.COLSTATS = True
+        assert torch.allclose(got.cpu(), two_pass.cpu(), rtol=2e-5, atol=2e-6)
+        ref = F.conv2d(_untokens(x.cpu(), Nimg, H, W).float(), _h(w).float(), None, padding=1)
+        assert out.shape == (T, 512) and torch.isfinite(out).all() and ref.shape[1] == 512
+    finally:
+        L.lkgd_debug_set_gemm_variant(0)
+        L.lkgd_debug_set_wide_lds_out(-1)
+
+
 def test_attn_cross_short_contexts():
     """lkgd_attn_cross: every row against the Lk keys of the context its row map selects (block-constant and interleaved
     maps, a table that starts at a later context, ragged T) vs fp32 softmax attention"""
