@@ -122,6 +122,7 @@ int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d);
  * idle more than a tenth of their columns (N = 256, 512, 768: the temporal VAE decoder's widths, diffusers
  * AutoencoderKLTemporalDecoder block_out_channels (128, 256, 512, 512)) - introspection for tests and tools */
 int lkgd_gemm_wide_tile_n(int N);
+void lkgd_debug_set_wide_tile_n(int wn);   /* A/B knob: force 256 / 320 where that width divides N; 0 = the rule */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 2. GroupNorm (32 groups) statistics + apply + SiLU on channels-last tokens.

@@ -60,6 +60,7 @@ SYMBOLS = {
     "lkgd_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "lkgd_gemm_colstats_block": (_i32, [C.POINTER(GemmDesc)]),
     "lkgd_gemm_wide_tile_n": (_i32, [_i32]),
+    "lkgd_debug_set_wide_tile_n": (None, [_i32]),
     "lkgd_groupnorm_stats_cols": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _vp, _vp]),
     "lkgd_groupnorm_chunks": (_i32, [_i64, _i32]),
     "lkgd_groupnorm_stats": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp]),

@@ -459,8 +459,9 @@ static int check_desc(const lkgd_gemm_desc* d) {
 }
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
-extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit);   // gemm_wide.hip
+extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit, int wn);   // gemm_wide.hip
 extern "C" int lkgd_gemm_wide_tile_n(int N);     // 320, or 256 for N = 256, 512, 768 ... (the 256x256 form of that program)
+extern "C" int lkgd_debug_wide_tile_n_forced();  // the A/B knob's value (0 = rules apply)
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
 extern "C" int lkgd_gemm_resw_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_resw.hip
 extern "C" int lkgd_gemm_resw_ok(const lkgd_gemm_desc* d, int cus);
@@ -650,6 +651,20 @@ static int gemm_wide_slices(const lkgd_gemm_desc* d, int cus, int pick, int wide
   return wide_ks >= 2 ? wide_ks : 1;
 }
 
+// tile columns of a 256x320-program launch: the N-only rule (lkgd_gemm_wide_tile_n), except that an unsliced plain linear
+// whose channel count BOTH widths divide (N = 1280, 3840 ...) takes 256-column tiles where they need no more CU rounds than
+// the 320-column ones: a 256-column tile costs ~0.85 of a 320-column one, so equal rounds mean less time.  That is the case
+// on sharded ranks - 8064 x 1280 x 1280 (a CFG-parallel rank's attention-out at the 18x32 level, 128 / 160 tiles) 52.9 ->
+// 44.2 us, 8064 x 3840 x 1280 (384 / 480 tiles: two rounds either way) 88.9 -> 80.0, 4032 x 3840 x 1280 48.9 -> 44.0 - and
+// never on the full forward (16 128 rows: 252 tiles fill one round, 315 need two; profiles/r05_wide_tile_n.txt)
+static int gemm_wide_n(const lkgd_gemm_desc* d, int cus, int slices) {
+  const int wn = lkgd_gemm_wide_tile_n(d->N);
+  if (lkgd_debug_wide_tile_n_forced() || wn != 320 || slices != 1 || d->mode != LKGD_A_PLAIN || d->geglu || d->N % 320 || d->N % 256) return wn;
+  const long long tm = (d->M + 255) / 256;
+  const long long r320 = (tm * (d->N / 320) + cus - 1) / cus, r256 = (tm * (d->N / 256) + cus - 1) / cus;
+  return r256 * 85 < r320 * 100 ? 256 : 320;
+}
+
 extern "C" int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d) {
   if (!d || check_desc(d) != LKGD_OK || d->geglu || d->N % 8) return 0;
   int cus = 0;
@@ -658,7 +673,7 @@ extern "C" int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d) {
   const int pick = gemm_pick(d, cus, &wide_ks);
   if (pick == 6) return lkgd_gemm_resw_colstats_ok(d) ? 32 : 0;
   // the 256x320 program sums the columns of the row segments it parks in LDS: whole 320-column tiles, unsliced K
-  if (pick == 4 && gemm_wide_slices(d, cus, pick, wide_ks) == 1 && d->N % lkgd_gemm_wide_tile_n(d->N) == 0 && d->ldc % 8 == 0 &&
+  if (pick == 4 && gemm_wide_slices(d, cus, pick, wide_ks) == 1 && d->N % gemm_wide_n(d, cus, 1) == 0 && d->ldc % 8 == 0 &&
       aligned16(d->out))
     return 256;
   return 0;
@@ -686,7 +701,7 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
   if (pick == 4) {
     const int ks = gemm_wide_slices(d, cus, pick, wide_ks);
-    rc = lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus, ks);
+    rc = lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus, ks, gemm_wide_n(d, cus, ks));
     if (rc != LKGD_OK || ks == 1) return rc;
     const int tn128 = (d->N + BN - 1) / BN;
     const unsigned rblocks = (unsigned)(((d->M + 31) / 32) * tn128);

@@ -544,11 +544,15 @@ extern "C" void lkgd_debug_set_wide_lds_out(int on) { wide_lds_out_override = on
 
 // the 256x256 form serves channel counts that are whole 256-column tiles and not whole 320-column ones (256, 512, 768 ...)
 // and would leave more than a tenth of the 320-wide tile columns idle (3072 = 9.6 x 320 stays on 320)
+static int wide_tile_n_forced = 0;      // A/B knob (tools/micro/wide_tile_n.py): 256 / 320 where that width divides N, 0 = the rule
+extern "C" void lkgd_debug_set_wide_tile_n(int wn) { wide_tile_n_forced = (wn == 256 || wn == 320) ? wn : 0; }
+extern "C" int lkgd_debug_wide_tile_n_forced() { return wide_tile_n_forced; }
 extern "C" int lkgd_gemm_wide_tile_n(int N) {
+  if (wide_tile_n_forced && N % wide_tile_n_forced == 0) return wide_tile_n_forced;
   return (N % WBN != 0 && N % 256 == 0 && (long long)((N + WBN - 1) / WBN) * WBN * 10 > (long long)N * 11) ? 256 : WBN;
 }
 
-extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit) {
+extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit, int wn) {
 #define WIDE_FN(...) (const void*)lkgd_gemm_wide_kernel<__VA_ARGS__>
   LKGD_DEVICE_ONCE_BEGIN
     const void* fns[] = {WIDE_FN(LKGD_A_PLAIN, false), WIDE_FN(LKGD_A_CONV3X3, false), WIDE_FN(LKGD_A_TCONV3, false),
@@ -561,7 +565,7 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) != hipSuccess) return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
 #undef WIDE_FN
-  const int wn = lkgd_gemm_wide_tile_n(d->N);
+  if (wn != 256 && wn != WBN) return LKGD_E_SHAPE;            // the caller's choice of tile columns (gemm.hip: gemm_wide_n)
   int tiles_m = (d->M + WBM - 1) / WBM, tiles_n = (d->N + wn - 1) / wn;
   if (ksplit < 1 || (d->K / BK) % ksplit || (ksplit > 1 && (!d->workspace || d->geglu))) return LKGD_E_SHAPE;
   if (wn == 256 && (ksplit > 1 || d->geglu)) return LKGD_E_SHAPE;       // K slices and the GEGLU interleave exist for 320-column tiles only

@@ -345,8 +345,10 @@ LN_QKV = os.environ.get("LKGD_NO_LN_QKV", "0") != "1"
 
 
 def ln_qkv_ok(T: int, N: int, C_: int) -> bool:
-    """the fused kernel exists for 320 -> 960 and 640 -> 1920 and pays where its 128-token panels fill the CUs (about) twice over"""
-    return LN_QKV and C_ in (320, 640) and N == 3 * C_ and T >= 60000
+    """the fused kernel exists for 320 -> 960 and 640 -> 1920 and pays where its 128-token panels fill the CUs: from one full
+    round at C = 640 (a CFG-parallel rank's 32 256 rows: 83 us against 109 for LayerNorm + GEMM; 16 128 rows tie), from two
+    at C = 320, where the alternative is the row-panel GEMM with the LayerNorm folded in (profiles/r05_ln_qkv_rows.txt)"""
+    return LN_QKV and C_ in (320, 640) and N == 3 * C_ and T >= (30000 if C_ == 640 else 60000)
 
 
 def ln_qkv(x: torch.Tensor, wstream: torch.Tensor, out: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

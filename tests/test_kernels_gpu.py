@@ -777,6 +777,20 @@ def test_gemm_wide_256_column_tiles():
     finally:
         L.lkgd_debug_set_gemm_variant(0)
         L.lkgd_debug_set_wide_lds_out(-1)
+    # the dispatcher's own choice between the two widths where both divide N (a CFG-parallel rank's 18x32 level: 8064 rows,
+    # N = 1280 / 3840 -> 256-column tiles; 16 128 rows -> 320): same result under either forced width
+    for M, N, K in ((8064, 1280, 1280), (8064, 3840, 1280), (16128, 1280, 1280)):
+        a, w = _h(torch.randn(M, K, generator=g)).to(DEV), _h(torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+        b, res = torch.randn(N, generator=g).to(DEV), _h(torch.randn(M, N, generator=g)).to(DEV)
+        outs = []
+        for wn in (0, 256, 320):
+            L.lkgd_debug_set_wide_tile_n(wn)
+            o = torch.empty(M, N, dtype=torch.float16, device=DEV)
+            ops.gemm(a, w, o, M=M, N=N, K=K, bias=b, res1=res)
+            outs.append(o)
+        L.lkgd_debug_set_wide_tile_n(0)
+        _close(outs[0], (a.float() @ w.float().T + b + res.float()).cpu(), what=f"auto width {M}x{N}x{K}")
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])      # same K order per output element
 
 
 def test_attn_cross_short_contexts():
