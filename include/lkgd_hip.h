@@ -111,7 +111,9 @@ typedef struct lkgd_gemm_desc {
                               tensor is never written.  Plain A, K = the LayerNorm's width <= 320 (K % 64 == 0), no GEGLU:
                               the row-panel program; LKGD_E_SHAPE otherwise. */
   float ln_eps;            /* the LayerNorm's epsilon (with ln_colsum) */
-  int32_t ln_pad_;         /* keeps the struct size a multiple of 8 */
+  int32_t cs_rows;         /* rows per GroupNorm sample of the tensor's consumer when `colstats` is (or is about to be) asked for,
+                              0 = unknown: the tile-form choice then only considers tile rows that divide it (a 192-row form
+                              would otherwise void the column sums of a 512-row sample).  Set it before lkgd_gemm_colstats_block */
 } lkgd_gemm_desc;
 
 int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream);
@@ -123,6 +125,7 @@ int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d);
  * AutoencoderKLTemporalDecoder block_out_channels (128, 256, 512, 512)) - introspection for tests and tools */
 int lkgd_gemm_wide_tile_n(int N);
 void lkgd_debug_set_wide_tile_n(int wn);   /* A/B knob: force 256 / 320 where that width divides N; 0 = the rule */
+void lkgd_debug_set_wide_tile_m(int wm);   /* A/B knob: force 192 / 256 tile rows on unsliced launches of that program; 0 = the rule */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 2. GroupNorm (32 groups) statistics + apply + SiLU on channels-last tokens.

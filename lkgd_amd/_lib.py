@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
         ("geglu", C.c_int32), ("pad_off", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("colstats", C.c_void_p),
-        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_pad_", C.c_int32),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("cs_rows", C.c_int32),
     ]
 
 
@@ -61,6 +61,7 @@ SYMBOLS = {
     "lkgd_gemm_colstats_block": (_i32, [C.POINTER(GemmDesc)]),
     "lkgd_gemm_wide_tile_n": (_i32, [_i32]),
     "lkgd_debug_set_wide_tile_n": (None, [_i32]),
+    "lkgd_debug_set_wide_tile_m": (None, [_i32]),
     "lkgd_groupnorm_stats_cols": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _vp, _vp]),
     "lkgd_groupnorm_chunks": (_i32, [_i64, _i32]),
     "lkgd_groupnorm_stats": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp]),

@@ -459,9 +459,10 @@ static int check_desc(const lkgd_gemm_desc* d) {
 }
 
 extern "C" int lkgd_gemm_stream_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);   // gemm_stream.hip
-extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit, int wn);   // gemm_wide.hip
+extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit, int wn, int wm);   // gemm_wide.hip
 extern "C" int lkgd_gemm_wide_tile_n(int N);     // 320, or 256 for N = 256, 512, 768 ... (the 256x256 form of that program)
 extern "C" int lkgd_debug_wide_tile_n_forced();  // the A/B knob's value (0 = rules apply)
+extern "C" int lkgd_debug_wide_tile_m_forced();
 extern "C" int lkgd_gemm_rowpanel_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus); // gemm_rowpanel.hip
 extern "C" int lkgd_gemm_resw_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus);     // gemm_resw.hip
 extern "C" int lkgd_gemm_resw_ok(const lkgd_gemm_desc* d, int cus);
@@ -651,18 +652,37 @@ static int gemm_wide_slices(const lkgd_gemm_desc* d, int cus, int pick, int wide
   return wide_ks >= 2 ? wide_ks : 1;
 }
 
-// tile columns of a 256x320-program launch: the N-only rule (lkgd_gemm_wide_tile_n), except that an unsliced plain linear
-// whose channel count BOTH widths divide (N = 1280, 3840 ...) takes 256-column tiles where they need no more CU rounds than
-// the 320-column ones: a 256-column tile costs ~0.85 of a 320-column one, so equal rounds mean less time.  That is the case
-// on sharded ranks - 8064 x 1280 x 1280 (a CFG-parallel rank's attention-out at the 18x32 level, 128 / 160 tiles) 52.9 ->
-// 44.2 us, 8064 x 3840 x 1280 (384 / 480 tiles: two rounds either way) 88.9 -> 80.0, 4032 x 3840 x 1280 48.9 -> 44.0 - and
-// never on the full forward (16 128 rows: 252 tiles fill one round, 315 need two; profiles/r05_wide_tile_n.txt)
-static int gemm_wide_n(const lkgd_gemm_desc* d, int cus, int slices) {
-  const int wn = lkgd_gemm_wide_tile_n(d->N);
-  if (lkgd_debug_wide_tile_n_forced() || wn != 320 || slices != 1 || d->mode != LKGD_A_PLAIN || d->geglu || d->N % 320 || d->N % 256) return wn;
-  const long long tm = (d->M + 255) / 256;
-  const long long r320 = (tm * (d->N / 320) + cus - 1) / cus, r256 = (tm * (d->N / 256) + cus - 1) / cus;
-  return r256 * 85 < r320 * 100 ? 256 : 320;
+// Tile form of an unsliced 256x320-program launch: tile rows wm (256 | 192: wave tile 64 | 48 rows) x tile columns wn (320 | 256).
+// The N-only rule (lkgd_gemm_wide_tile_n) fixes wn where only one width divides N; a plain linear whose channel count BOTH widths
+// divide (1280, 3840) may take either.  Among the candidates the one with the smallest MODELLED time wins: rounds over the CUs
+// x the cost of one tile of that form relative to 256x320 - 1.00 | 0.85 (256x256) | 0.83 (192x320) | 0.72 (192x256), measured
+// on one-round shapes (tools/micro/wide_tile_m.py, profiles/r05_wide_tile_m.txt: 36 864 x 320 x 2880 conv 88.8 -> 75.5 us,
+// 16 128 x 640 x 5760 conv 154.7 -> 127.7, 8064 x 1280 x 1280 51.6 -> 43.7 / 42.5 / 37.1) - and a smaller tile must win by 3 %.
+// On the full forward every large shape keeps 256x320 (1008 tiles = 4 rounds against 1344 = 6 x 0.83); the smaller forms are
+// for the levels of a sharded rank, where 256-row tiles leave CUs idle.
+static void gemm_wide_form(const lkgd_gemm_desc* d, int cus, int slices, int* wn_out, int* wm_out) {
+  const int wn0 = lkgd_gemm_wide_tile_n(d->N);
+  *wn_out = wn0;
+  *wm_out = 256;
+  if (slices != 1 || d->geglu) return;
+  const int fn = lkgd_debug_wide_tile_n_forced(), fm = lkgd_debug_wide_tile_m_forced();
+  if (fn || fm) {                                  // A/B knobs: no rule
+    if (fm) *wm_out = fm;
+    return;
+  }
+  const bool both = wn0 == 320 && d->mode == LKGD_A_PLAIN && d->N % 320 == 0 && d->N % 256 == 0;
+  float best = 0.f;
+  for (int pass = 0; pass < 4; ++pass) {           // 256x wn0 first: the default, to which the others are compared
+    const int wm = (pass & 1) ? 192 : 256, wn = (pass & 2) ? 256 : wn0;
+    if ((pass & 2) && !both) continue;
+    if (pass && d->cs_rows > 0 && d->cs_rows % wm) continue;       // column sums: whole tiles per GroupNorm sample
+    const long long tiles = (long long)((d->M + wm - 1) / wm) * ((d->N + wn - 1) / wn);
+    const long long rounds = (tiles + cus - 1) / cus;
+    const float unit = (wn == 256 ? 0.85f : 1.0f) * (wm == 192 ? (wn == 256 ? 0.72f / 0.85f : 0.83f) : 1.0f);
+    const float cost = (float)rounds * unit;
+    if (pass == 0) best = cost;
+    else if (cost < best * 0.97f) { best = cost; *wn_out = wn; *wm_out = wm; }
+  }
 }
 
 extern "C" int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d) {
@@ -673,9 +693,11 @@ extern "C" int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d) {
   const int pick = gemm_pick(d, cus, &wide_ks);
   if (pick == 6) return lkgd_gemm_resw_colstats_ok(d) ? 32 : 0;
   // the 256x320 program sums the columns of the row segments it parks in LDS: whole 320-column tiles, unsliced K
-  if (pick == 4 && gemm_wide_slices(d, cus, pick, wide_ks) == 1 && d->N % gemm_wide_n(d, cus, 1) == 0 && d->ldc % 8 == 0 &&
-      aligned16(d->out))
-    return 256;
+  if (pick == 4 && gemm_wide_slices(d, cus, pick, wide_ks) == 1 && d->ldc % 8 == 0 && aligned16(d->out)) {
+    int wn, wm;
+    gemm_wide_form(d, cus, 1, &wn, &wm);
+    return d->N % wn == 0 ? wm : 0;
+  }
   return 0;
 }
 
@@ -701,7 +723,9 @@ extern "C" int lkgd_gemm_f16(const lkgd_gemm_desc* d, lkgd_stream_t stream) {
   if (pick == 5) return lkgd_gemm_rowpanel_launch(d, (hipStream_t)stream, cus);
   if (pick == 4) {
     const int ks = gemm_wide_slices(d, cus, pick, wide_ks);
-    rc = lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus, ks, gemm_wide_n(d, cus, ks));
+    int wn, wm;
+    gemm_wide_form(d, cus, ks, &wn, &wm);
+    rc = lkgd_gemm_wide_launch(d, (hipStream_t)stream, cus, ks, wn, wm);
     if (rc != LKGD_OK || ks == 1) return rc;
     const int tn128 = (d->N + BN - 1) / BN;
     const unsigned rblocks = (unsigned)(((d->M + 31) / 32) * tn128);

@@ -81,7 +81,7 @@ struct WideIn {                 // what one K-tile body needs about the NEXT K-t
 
 // statement A: barrier, K-step 0 (fragment reads, the nine DMA loads of the next K-tile, 40 MFMAs) and the reads of K-step 1's
 // first fragments, which leave in x1 / w0
-template <bool FIRST, int NF>
+template <bool FIRST, int NF, int MF>
 __device__ __forceinline__ void wide_ktile_a(half8_t (&x1)[4], half8_t& w0, int xa0, int xa1, int wa0, int wa1,
                                              const half_t* const (&pA)[4], const WideIn& in, int m_a) {
   half8_t x0, x1_, x2, x3, w1;
@@ -92,7 +92,19 @@ __device__ __forceinline__ void wide_ktile_a(half8_t (&x1)[4], half8_t& w0, int 
                : "v"(xa0), "v"(xa1), "v"(wa0), "v"(wa1), "v"(pA[0]), "v"(pA[1]), "v"(pA[2]), "v"(pA[3]),               \
                  "v"(in.oB[0]), "v"(in.oB[1]), "v"(in.oB[2]), "v"(in.oB[3]), "v"(in.oB[4]), "s"(in.wk), "s"(m_a)       \
                : "memory", "scc", WIDE_AGPR_CLOBBERS)
-  if (NF == 8) {              // the 256x256 form: eight weight fragments per wave, four weight loads per thread (in.oB[4] unused)
+  if (MF == 3) {              // the 192-row forms: three token fragments per wave, three token loads per thread (x0[3], x1[3], pA[3] unused)
+    if (NF == 8) {
+      if (FIRST) {
+        WIDE_STMT(WIDE8_M3_KTILE_ASM_FIRST_A);
+      } else {
+        WIDE_STMT(WIDE8_M3_KTILE_ASM_NEXT_A);
+      }
+    } else if (FIRST) {
+      WIDE_STMT(WIDE_M3_KTILE_ASM_FIRST_A);
+    } else {
+      WIDE_STMT(WIDE_M3_KTILE_ASM_NEXT_A);
+    }
+  } else if (NF == 8) {       // the 256x256 form: eight weight fragments per wave, four weight loads per thread (in.oB[4] unused)
     if (FIRST) {
       WIDE_STMT(WIDE8_KTILE_ASM_FIRST_A);
     } else {
@@ -108,10 +120,18 @@ __device__ __forceinline__ void wide_ktile_a(half8_t (&x1)[4], half8_t& w0, int 
 
 // statement B: K-step 1 (40 MFMAs).  The C++ between A and B prepares the NEXT K-tile's sources while K-step 0's MFMAs drain
 // (between two K-tiles it would sit behind the barrier with the matrix pipe idle).
-template <int NF>
+template <int NF, int MF>
 __device__ __forceinline__ void wide_ktile_b(const half8_t (&x1)[4], half8_t w0, int wa1) {
   half8_t w1;
-  if (NF == 8)
+#define WIDE_STMT_B(BODY)                                                  \
+  asm volatile(BODY                                                        \
+               : "=&v"(w1), "+v"(w0)                                       \
+               : "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]), "v"(wa1)  \
+               : "memory", WIDE_AGPR_CLOBBERS)
+  if (MF == 3) {
+    if (NF == 8) WIDE_STMT_B(WIDE8_M3_KTILE_ASM_B);
+    else WIDE_STMT_B(WIDE_M3_KTILE_ASM_B);
+  } else if (NF == 8)
     asm volatile(WIDE8_KTILE_ASM_B
                  : "=&v"(w1), "+v"(w0)
                  : "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]), "v"(wa1)
@@ -121,6 +141,7 @@ __device__ __forceinline__ void wide_ktile_b(const half8_t (&x1)[4], half8_t w0,
                  : "=&v"(w1), "+v"(w0)
                  : "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]), "v"(wa1)
                  : "memory", WIDE_AGPR_CLOBBERS);
+#undef WIDE_STMT_B
 }
 
 // accumulator fragment (weight fragment i, token fragment j) out of the AGPRs; BASE = (4i + j) * 4
@@ -155,9 +176,15 @@ template <class F> __device__ __forceinline__ void wide_for5(F&& f) {
 // NF = weight fragments per wave: 10 = the 256x320 tile (wave tile 64 x 160), 8 = the 256x256 tile (64 x 128) for channel
 // counts that are multiples of 256 and not of 320 (the VAE decoder's 256 / 512).  The LDS map is the 256x320 one in both
 // forms (the weight part of a stage is filled to 32 of its 40 KiB), so is everything outside the constants below.
-template <int MODE, bool SPLIT, bool LDSOUT, int NF>
+// MF = token fragments per wave: 4 = 256-row tiles (wave tile 64 rows), 3 = 192-row tiles (48 rows) for row counts whose
+// 256-row tiles leave CUs idle (a sharded rank's levels): the same LDS map with the token part of a stage filled to 24 of
+// its 32 KiB.
+template <int MODE, bool SPLIT, bool LDSOUT, int NF, int MF>
 __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, int tiles_n, int ksplit_arg, float* ws) {
   static_assert(NF == 10 || (NF == 8 && !SPLIT), "wave tiles: 64 x 160 or 64 x 128 (the latter unsliced)");
+  static_assert(MF == 4 || (MF == 3 && !SPLIT), "wave tiles: 64 or 48 rows (the latter unsliced)");
+  constexpr int WM = 64 * MF;       // tile rows
+  constexpr int WRW = 16 * MF;      // a wave's rows
   constexpr int WN = 32 * NF;       // tile columns
   constexpr int WCH = 16 * NF;      // a wave's channels
   const int ksplit = SPLIT ? ksplit_arg : 1;
@@ -224,7 +251,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
         supertile<4>(st_tile / ksplit, tiles_m, tiles_n, tm, tn);
         st_k0 = SPLIT ? (st_tile % ksplit) * nk : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ag.rd[i] = lean_row<MODE>(p, WIDE_A_ROW(tm * WBM) + srow + 64 * i, rcp0, rcp1);
+        for (int i = 0; i < MF; ++i) ag.rd[i] = lean_row<MODE>(p, WIDE_A_ROW(tm * WM) + srow + 64 * i, rcp0, rcp1);   // (rows past MF stay on the zero page)
 #pragma unroll
         for (int i = 0; i < NF / 2; ++i) {
           int n = tn * WN + srow + 64 * i;
@@ -243,8 +270,8 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
         if (rb_lds && w >= 5) {
           // waves 5-7 fetch dwords (w-5)*64 + lane of the two 160-dword strips (lanes past 160 re-read the last dword
           // into the strip's padding)
-          const unsigned mf = (unsigned)(tm * WBM);
-          unsigned ml = mf + WBM - 1;
+          const unsigned mf = (unsigned)(tm * WM);
+          unsigned ml = mf + WM - 1;
           ml = ml < (unsigned)p.M ? ml : (unsigned)p.M - 1;
           const unsigned i0 = ((mf / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (unsigned)p.rb_c0) % (unsigned)p.rb_md;
           const unsigned i1 = ((ml / (unsigned)p.rb_d1) * (unsigned)p.rb_m1 + (unsigned)p.rb_c0) % (unsigned)p.rb_md;
@@ -279,7 +306,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
   const int skey = (l15 >> 1) & 7;
   int xa0, xa1, wa0, wa1;       // LDS addresses of fragment 0 (tokens / weights, K-step 0 / 1) in the CURRENT stage
   {
-    const int x_base = (wr * 64 + l15) * 128;
+    const int x_base = (wr * WRW + l15) * 128;
     const int w_base = WBM * BK * 2 + (wc * WCH + l15) * 128;
     const int ch0 = ((0 + lq) ^ skey) << 4, ch1 = ((4 + lq) ^ skey) << 4;
     xa0 = x_base + ch0; xa1 = x_base + ch1; wa0 = w_base + ch0; wa1 = w_base + ch1;
@@ -290,7 +317,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
     next_in(in);
     char* sx = smem + w * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(ag.aptr[i], sx + 8192 * i);
+    for (int i = 0; i < MF; ++i) glds16(ag.aptr[i], sx + 8192 * i);
 #pragma unroll
     for (int i = 0; i < NF / 2; ++i) glds16((const half_t*)((const char*)in.wk + in.oB[i]), sx + WBM * BK * 2 + 8192 * i);
   }
@@ -323,11 +350,11 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
 #endif
     const int m_a = (cur ^ 1) * WSTAGE_BYTES + w * 1024;
     half8_t x1[4], w0;
-    if (kt == 0) wide_ktile_a<true, NF>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
-    else wide_ktile_a<false, NF>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    if (kt == 0) wide_ktile_a<true, NF, MF>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
+    else wide_ktile_a<false, NF, MF>(x1, w0, xa0, xa1, wa0, wa1, ag.aptr, in, m_a);
     const int wa1_now = wa1;
     next_in(in);                // K-tile s+2's sources, for the next body
-    wide_ktile_b<NF>(x1, w0, wa1_now);
+    wide_ktile_b<NF, MF>(x1, w0, wa1_now);
     {
       const int d = cur ? -WSTAGE_BYTES : WSTAGE_BYTES;      // the other stage becomes the current one
       xa0 += d; xa1 += d; wa0 += d; wa1 += d;
@@ -350,7 +377,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
       supertile<4>(tile / ksplit, tiles_m, tiles_n, tm, tn);
       const int slice = tile % ksplit;
       tile += nc;
-      const int m0 = tm * WBM + wr * 64 + l15;
+      const int m0 = tm * WM + wr * WRW + l15;
       const int n0 = tn * WN + wc * WCH + 4 * lq;
       const half_t* rbp = (const half_t*)p.rowbias;
       const half_t* r1p = (const half_t*)p.res1;
@@ -361,7 +388,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
       const float* bl = (const float*)(smem + WBIAS_OFF + ep_par * (WBN * 4)) + wc * WCH + 4 * lq;   // bias[n0 + ...]
       const half_t* rbl = (const half_t*)(smem + WRB_OFF + ep_par * (2 * WRB_STRIP)) + wc * WCH + 4 * lq;
       // rows below rb_bound use the first strip, the others the second (the map changes at most once inside the tile)
-      const unsigned rb_bound = rb_lds ? ((unsigned)(tm * WBM) / (unsigned)p.rb_d1 + 1u) * (unsigned)p.rb_d1 : 0u;
+      const unsigned rb_bound = rb_lds ? ((unsigned)(tm * WM) / (unsigned)p.rb_d1 + 1u) * (unsigned)p.rb_d1 : 0u;
       // Output rows through LDS (LDSOUT: the plain linears without GEGLU).  In the accumulator layout a lane holds 4 channels
       // of ONE token row, so a direct store instruction writes 16 rows x 32 bytes; a CU sustains ~16 GB/s of those against
       // 24-60 GB/s for 16-byte pieces of contiguous rows (tools/micro/store_bw.hip), and the short-K linears are store-bound
@@ -456,7 +483,7 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
         if (lds_out) {
           // the fragment's rows as 16-byte pieces: piece c of the wave's 16 x (20 | 10) grid -> row c / per, column piece c % per
           const int per = gg ? 10 : 2 * NF;                           // 16-byte pieces per row (80 | 160 | 128 channels)
-          const long long mrow0 = (long long)tm * WBM + wr * 64 + j * 16;
+          const long long mrow0 = (long long)tm * WM + wr * WRW + j * 16;
           if (cs_on && lane_e < 4 * NF) {
             // branch-free over the 16 rows (rows past M are weighted 0): the reads issue back to back; per channel PAIR
             // one v_dot2_f32_f16 for the sum and one for the sum of squares (fp16 products are exact in fp32)
@@ -498,7 +525,8 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
     epi(WideIC<J>{});                                                                                              \
     __builtin_amdgcn_sched_barrier(0);  /* keep one token fragment's loads/stores from piling onto the next */   \
   }
-      WIDE_EPI(0) WIDE_EPI(1) WIDE_EPI(2) WIDE_EPI(3)
+      WIDE_EPI(0) WIDE_EPI(1) WIDE_EPI(2)
+      if constexpr (MF == 4) WIDE_EPI(3)
 #undef WIDE_EPI
       if (cs_on) {
         // [row group wr][160 channel pairs][sum, sum of squares] behind the eight waves' row patches in the free stage; the
@@ -529,13 +557,13 @@ __device__ __forceinline__ void wide_body(const lkgd_gemm_desc& p, int tiles_m, 
 #endif
 }
 
-template <int MODE, bool LDSOUT, int NF = 10>
+template <int MODE, bool LDSOUT, int NF = 10, int MF = 4>
 __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n) {
-  wide_body<MODE, false, LDSOUT, NF>(p, tiles_m, tiles_n, 1, nullptr);
+  wide_body<MODE, false, LDSOUT, NF, MF>(p, tiles_m, tiles_n, 1, nullptr);
 }
 template <int MODE>
 __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void lkgd_gemm_wide_split_kernel(const lkgd_gemm_desc p, int tiles_m, int tiles_n, int ksplit, float* ws) {
-  wide_body<MODE, true, false, 10>(p, tiles_m, tiles_n, ksplit, ws);
+  wide_body<MODE, true, false, 10, 4>(p, tiles_m, tiles_n, ksplit, ws);
 }
 
 // ksplit > 1: K is cut into ksplit equal slices (ksplit divides K / 64); the caller runs lkgd_gemm_splitk_reduce afterwards
@@ -547,28 +575,50 @@ extern "C" void lkgd_debug_set_wide_lds_out(int on) { wide_lds_out_override = on
 static int wide_tile_n_forced = 0;      // A/B knob (tools/micro/wide_tile_n.py): 256 / 320 where that width divides N, 0 = the rule
 extern "C" void lkgd_debug_set_wide_tile_n(int wn) { wide_tile_n_forced = (wn == 256 || wn == 320) ? wn : 0; }
 extern "C" int lkgd_debug_wide_tile_n_forced() { return wide_tile_n_forced; }
+static int wide_tile_m_forced = 0;      // A/B knob: 192 / 256 tile rows (0 = the rule of gemm.hip::gemm_wide_form)
+extern "C" void lkgd_debug_set_wide_tile_m(int wm) { wide_tile_m_forced = (wm == 192 || wm == 256) ? wm : 0; }
+extern "C" int lkgd_debug_wide_tile_m_forced() { return wide_tile_m_forced; }
 extern "C" int lkgd_gemm_wide_tile_n(int N) {
   if (wide_tile_n_forced && N % wide_tile_n_forced == 0) return wide_tile_n_forced;
   return (N % WBN != 0 && N % 256 == 0 && (long long)((N + WBN - 1) / WBN) * WBN * 10 > (long long)N * 11) ? 256 : WBN;
 }
 
-extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit, int wn) {
-#define WIDE_FN(...) (const void*)lkgd_gemm_wide_kernel<__VA_ARGS__>
+template <int MODE>
+static void wide_go(const lkgd_gemm_desc* d, hipStream_t stream, int grid, int tiles_m, int tiles_n, bool lds_out, int wn, int wm) {
+#define WIDE_GO(...) \
+  hipLaunchKernelGGL((lkgd_gemm_wide_kernel<MODE, __VA_ARGS__>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n)
+  if (wm == 192) {
+    if (wn == 256) { if (lds_out) WIDE_GO(true, 8, 3); else WIDE_GO(false, 8, 3); }
+    else { if (lds_out) WIDE_GO(true, 10, 3); else WIDE_GO(false, 10, 3); }
+  } else {
+    if (wn == 256) { if (lds_out) WIDE_GO(true, 8, 4); else WIDE_GO(false, 8, 4); }
+    else { if (lds_out) WIDE_GO(true, 10, 4); else WIDE_GO(false, 10, 4); }
+  }
+#undef WIDE_GO
+}
+template <int MODE>
+static bool wide_set_lds(const void* split_fn) {
+  const void* fns[] = {(const void*)lkgd_gemm_wide_kernel<MODE, false, 10, 4>, (const void*)lkgd_gemm_wide_kernel<MODE, true, 10, 4>,
+                       (const void*)lkgd_gemm_wide_kernel<MODE, false, 8, 4>,  (const void*)lkgd_gemm_wide_kernel<MODE, true, 8, 4>,
+                       (const void*)lkgd_gemm_wide_kernel<MODE, false, 10, 3>, (const void*)lkgd_gemm_wide_kernel<MODE, true, 10, 3>,
+                       (const void*)lkgd_gemm_wide_kernel<MODE, false, 8, 3>,  (const void*)lkgd_gemm_wide_kernel<MODE, true, 8, 3>, split_fn};
+  for (const void* f : fns)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) != hipSuccess) return false;
+  return true;
+}
+
+// wn = tile columns (320 | 256), wm = tile rows (256 | 192): the caller's choice (gemm.hip: gemm_wide_form)
+extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream, int cus, int ksplit, int wn, int wm) {
   LKGD_DEVICE_ONCE_BEGIN
-    const void* fns[] = {WIDE_FN(LKGD_A_PLAIN, false), WIDE_FN(LKGD_A_CONV3X3, false), WIDE_FN(LKGD_A_TCONV3, false),
-                         WIDE_FN(LKGD_A_PLAIN, true), WIDE_FN(LKGD_A_CONV3X3, true), WIDE_FN(LKGD_A_TCONV3, true),
-                         (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>, (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>,
-                         (const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>,
-                         WIDE_FN(LKGD_A_PLAIN, false, 8), WIDE_FN(LKGD_A_CONV3X3, false, 8), WIDE_FN(LKGD_A_TCONV3, false, 8),
-                         WIDE_FN(LKGD_A_PLAIN, true, 8), WIDE_FN(LKGD_A_CONV3X3, true, 8), WIDE_FN(LKGD_A_TCONV3, true, 8)};
-    for (const void* f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS) != hipSuccess) return LKGD_E_LAUNCH;
+    if (!wide_set_lds<LKGD_A_PLAIN>((const void*)lkgd_gemm_wide_split_kernel<LKGD_A_PLAIN>) ||
+        !wide_set_lds<LKGD_A_CONV3X3>((const void*)lkgd_gemm_wide_split_kernel<LKGD_A_CONV3X3>) ||
+        !wide_set_lds<LKGD_A_TCONV3>((const void*)lkgd_gemm_wide_split_kernel<LKGD_A_TCONV3>))
+      return LKGD_E_LAUNCH;
   LKGD_DEVICE_ONCE_END
-#undef WIDE_FN
-  if (wn != 256 && wn != WBN) return LKGD_E_SHAPE;            // the caller's choice of tile columns (gemm.hip: gemm_wide_n)
-  int tiles_m = (d->M + WBM - 1) / WBM, tiles_n = (d->N + wn - 1) / wn;
+  if ((wn != 256 && wn != WBN) || (wm != 192 && wm != WBM)) return LKGD_E_SHAPE;
+  int tiles_m = (d->M + wm - 1) / wm, tiles_n = (d->N + wn - 1) / wn;
   if (ksplit < 1 || (d->K / BK) % ksplit || (ksplit > 1 && (!d->workspace || d->geglu))) return LKGD_E_SHAPE;
-  if (wn == 256 && (ksplit > 1 || d->geglu)) return LKGD_E_SHAPE;       // K slices and the GEGLU interleave exist for 320-column tiles only
+  if ((wn == 256 || wm == 192) && (ksplit > 1 || d->geglu)) return LKGD_E_SHAPE;   // K slices and the GEGLU interleave exist for 256x320 tiles only
   long long ntiles = (long long)tiles_m * tiles_n * ksplit;
   if (ntiles > 0x7fffffffLL) return LKGD_E_SHAPE;
   int grid = ntiles < cus ? (int)ntiles : cus;
@@ -579,23 +629,17 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
   const bool lds_ok = ksplit == 1 && !d->geglu && d->N % wn == 0 && d->ldc % 8 == 0 && aligned16(d->out);
   if (d->colstats && !lds_ok) return LKGD_E_SHAPE;
   const bool lds_out = lds_ok && (d->colstats ? true : (wide_lds_out_override != 0 && d->mode == LKGD_A_PLAIN));
-#define WIDE_GO(...) \
-  hipLaunchKernelGGL((lkgd_gemm_wide_kernel<__VA_ARGS__>), dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n)
 #define WIDE_LAUNCH(MODE_)                                                                                              \
   {                                                                                                                     \
     if (ksplit > 1)                                                                                                     \
       hipLaunchKernelGGL(lkgd_gemm_wide_split_kernel<MODE_>, dim3(grid), dim3(WNT), WLDS, stream, *d, tiles_m, tiles_n, ksplit, ws); \
-    else if (wn == 256) {                                                                                               \
-      if (lds_out) WIDE_GO(MODE_, true, 8); else WIDE_GO(MODE_, false, 8);                                              \
-    } else {                                                                                                            \
-      if (lds_out) WIDE_GO(MODE_, true, 10); else WIDE_GO(MODE_, false, 10);                                            \
-    }                                                                                                                   \
+    else                                                                                                                \
+      wide_go<MODE_>(d, stream, grid, tiles_m, tiles_n, lds_out, wn, wm);                                               \
   }
   if (d->mode == LKGD_A_PLAIN) WIDE_LAUNCH(LKGD_A_PLAIN)
   else if (d->mode == LKGD_A_CONV3X3) WIDE_LAUNCH(LKGD_A_CONV3X3)
   else if (d->mode == LKGD_A_TCONV3) WIDE_LAUNCH(LKGD_A_TCONV3)
 #undef WIDE_LAUNCH
-#undef WIDE_GO
   else
     return LKGD_E_MODE;
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;

@@ -163,6 +163,7 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
         _req(ln[0], torch.float32, "ln colsum")
         d.ln_colsum, d.ln_eps = ln[0].data_ptr(), float(ln[1])
     if colstats and COLSTATS and out.shape[0] == M and out.shape[1] == N:
+        d.cs_rows = int(colstats)        # the tile-form choice keeps to tile rows that divide a sample
         blk = _L().lkgd_gemm_colstats_block(C.byref(d))
         if blk > 0 and int(colstats) % blk == 0:
             buf = torch.empty((M + blk - 1) // blk, N // 2, 2, dtype=torch.float32, device=out.device)   # channel pairs

@@ -632,8 +632,10 @@ def test_gemm_split_k_on_256x320_tiles():
         _close(out.cpu()[rows], a[rows].float() @ w.float().T + b, what=f"auto split {M}x{N}x{K}")
 
 
-def test_gemm_wide_rows_through_lds_match_direct_stores():
-    """the 256x320 kernel's two output paths (8-byte stores straight from the accumulator layout; whole 320-byte row
+@pytest.mark.parametrize("tile_rows", [256, 192])
+def test_gemm_wide_rows_through_lds_match_direct_stores(tile_rows):
+    """(both tile-row forms of the program: 256 rows, and 192 = wave tile 48 rows)
+    the 256x320 kernel's two output paths (8-byte stores straight from the accumulator layout; whole 320-byte row
     segments staged through LDS - the default for plain linears without GEGLU): bit-identical, on ragged M, a column-slice
     output (ldc > N), residual + row bias; rows past M and columns outside the slice stay untouched.  GEGLU and the
     convolutions keep the direct path under either setting."""
@@ -654,6 +656,7 @@ def test_gemm_wide_rows_through_lds_match_direct_stores():
         return outs[1]
 
     L.lkgd_debug_set_gemm_variant(4)
+    L.lkgd_debug_set_wide_tile_m(tile_rows)
     try:
         # plain, ragged M, residual + row bias, output = columns [64, 64+640) of a 768-wide buffer
         M, N, K = 256 * 5 + 77, 640, 320
@@ -698,10 +701,13 @@ def test_gemm_wide_rows_through_lds_match_direct_stores():
     finally:
         L.lkgd_debug_set_gemm_variant(0)
         L.lkgd_debug_set_wide_lds_out(-1)
+        L.lkgd_debug_set_wide_tile_m(0)
 
 
-def test_gemm_wide_256_column_tiles():
-    """the 256x256 form of the 256x320 program (wave tile 64 x 128: channel counts 256 / 512 / 768 - the VAE decoder's
+@pytest.mark.parametrize("tile_rows", [256, 192])
+def test_gemm_wide_256_column_tiles(tile_rows):
+    """(with 256- and 192-row tiles)
+    the 256x256 form of the 256x320 program (wave tile 64 x 128: channel counts 256 / 512 / 768 - the VAE decoder's
     widths): plain linear with bias + residual + both row-bias paths on ragged M and a column-slice output, 3x3 conv
     (stride 1, upsampled input), temporal conv; both output paths bit-identical; the GroupNorm sums of its epilogue"""
     from lkgd_amd import _lib, ops
@@ -723,6 +729,7 @@ def test_gemm_wide_256_column_tiles():
         return outs[1]
 
     L.lkgd_debug_set_gemm_variant(4)
+    L.lkgd_debug_set_wide_tile_m(tile_rows)
     try:
         for M, N, K, d1 in ((256 * 5 + 77, 512, 320, 300), (256 * 9, 256, 1024, 40), (700, 768, 128, 256)):
             a, w = _h(torch.randn(M, K, generator=g)), _h(torch.randn(N, K, generator=g) / K ** 0.5)
@@ -757,14 +764,14 @@ def test_gemm_wide_256_column_tiles():
         reft = F.conv3d(x5.float(), wt.float(), bt, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, C)
         _close(out, reft, what="256-column tconv")
         # GroupNorm sums from the epilogue: conv 128 -> 512 on 4 images of 16x32 (two tiles per image), against the read pass
-        Nimg, H, W = 4, 16, 32
+        Nimg, H, W = 4, 24, 32                  # 768 tokens per image: three 256-row tiles, four 192-row tiles
         T = Nimg * H * W
         x = _h(torch.randn(T, 128, generator=g)).to(DEV)
         w = torch.randn(512, 128, 3, 3, generator=g) / (9 * 128) ** 0.5
         out = torch.empty(T, 512, dtype=torch.float16, device=DEV)
         ops.gemm(x, pack_conv3x3(w).to(DEV), out, M=T, N=512, K=9 * 128, bias=torch.randn(512, generator=g).to(DEV),
                  mode=ops.A_CONV3X3, Cin=128, conv=(H, W, H, W, 1, 0), colstats=H * W)
-        assert out._lkgd_colstats[1] == 256
+        assert out._lkgd_colstats[1] == tile_rows
         got = ops.groupnorm_stats(out, None, Nimg, H * W, 1e-6)
         ops.COLSTATS = False
         try:
@@ -777,6 +784,7 @@ def test_gemm_wide_256_column_tiles():
     finally:
         L.lkgd_debug_set_gemm_variant(0)
         L.lkgd_debug_set_wide_lds_out(-1)
+        L.lkgd_debug_set_wide_tile_m(0)
     # the dispatcher's own choice between the two widths where both divide N (a CFG-parallel rank's 18x32 level: 8064 rows,
     # N = 1280 / 3840 -> 256-column tiles; 16 128 rows -> 320): same result under either forced width
     for M, N, K in ((8064, 1280, 1280), (8064, 3840, 1280), (16128, 1280, 1280)):
