@@ -664,13 +664,13 @@ static void gemm_wide_form(const lkgd_gemm_desc* d, int cus, int slices, int* wn
   const int wn0 = lkgd_gemm_wide_tile_n(d->N);
   *wn_out = wn0;
   *wm_out = 256;
-  if (slices != 1 || d->geglu) return;
+  if (slices != 1) return;
   const int fn = lkgd_debug_wide_tile_n_forced(), fm = lkgd_debug_wide_tile_m_forced();
   if (fn || fm) {                                  // A/B knobs: no rule
     if (fm) *wm_out = fm;
     return;
   }
-  const bool both = wn0 == 320 && d->mode == LKGD_A_PLAIN && d->N % 320 == 0 && d->N % 256 == 0;
+  const bool both = wn0 == 320 && d->mode == LKGD_A_PLAIN && !d->geglu && d->N % 320 == 0 && d->N % 256 == 0;   // (GEGLU: 80-wide interleave)
   float best = 0.f;
   for (int pass = 0; pass < 4; ++pass) {           // 256x wn0 first: the default, to which the others are compared
     const int wm = (pass & 1) ? 192 : 256, wn = (pass & 2) ? 256 : wn0;

@@ -618,7 +618,8 @@ extern "C" int lkgd_gemm_wide_launch(const lkgd_gemm_desc* d, hipStream_t stream
   if ((wn != 256 && wn != WBN) || (wm != 192 && wm != WBM)) return LKGD_E_SHAPE;
   int tiles_m = (d->M + wm - 1) / wm, tiles_n = (d->N + wn - 1) / wn;
   if (ksplit < 1 || (d->K / BK) % ksplit || (ksplit > 1 && (!d->workspace || d->geglu))) return LKGD_E_SHAPE;
-  if ((wn == 256 || wm == 192) && (ksplit > 1 || d->geglu)) return LKGD_E_SHAPE;   // K slices and the GEGLU interleave exist for 256x320 tiles only
+  if ((wn == 256 || wm == 192) && ksplit > 1) return LKGD_E_SHAPE;      // K slices: 256x320 tiles only
+  if (wn == 256 && d->geglu) return LKGD_E_SHAPE;                       // the 80-wide GEGLU interleave needs 320-column tiles
   long long ntiles = (long long)tiles_m * tiles_n * ksplit;
   if (ntiles > 0x7fffffffLL) return LKGD_E_SHAPE;
   int grid = ntiles < cus ? (int)ntiles : cus;
