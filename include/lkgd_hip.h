@@ -169,9 +169,12 @@ int lkgd_groupnorm_apply(const void* x0, int32_t c0, int32_t ld0, const void* x1
  * bit). */
 int lkgd_groupnorm_apply_segments(const void* segs, int32_t nseg, int64_t max_rows, int32_t C, int32_t ld, const float* stats,
                                   const float* gamma, const float* beta, int32_t silu, lkgd_stream_t stream);
-/* the whole F.group_norm (+ F.silu) of a tensor in one call: out = silu?(groupnorm(x)) = lkgd_groupnorm_stats followed by
- * lkgd_groupnorm_apply (the same three launches, the same numbers); `partial` as above, `stats` (nsamples*32*2 floats) receives
- * (mean, rstd). */
+/* the whole F.group_norm (+ F.silu) of a tensor in one call: out = silu?(groupnorm(x)).  Small maps - one (sample, group) =
+ * rows x C/32 channels of fp16 within 48 KiB, the tensor within 10.5 MB, at least 64 (sample, group) pairs: the 9x16 level and
+ * a sharded rank's 18x32 level - take ONE launch, a workgroup per pair
+ * (read once, statistics in fp32 sums / fp64 variance as lkgd_groupnorm_stats, normalised out of LDS; equal to the three
+ * launches up to the summation order of the statistics).  Otherwise lkgd_groupnorm_stats followed by lkgd_groupnorm_apply
+ * (the same three launches, the same numbers).  `partial` as above, `stats` (nsamples*32*2 floats) receives (mean, rstd). */
 int lkgd_groupnorm_silu(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1, int64_t nsamples,
                         int64_t rows_per_sample, float eps, float* partial, float* stats, const float* gamma,
                         const float* beta, int32_t silu, void* out, int32_t ldo, lkgd_stream_t stream);
@@ -490,6 +493,8 @@ void lkgd_debug_set_attn_pipe(int32_t mode);
 void lkgd_debug_set_gn_apply_kb(int32_t kb);
 void lkgd_debug_set_gn_stats_kb(int32_t kb);
 void lkgd_debug_set_gn_target_wgs(int32_t n);
+void lkgd_debug_set_gn_small(int32_t on);      /* 0 = lkgd_groupnorm_silu always takes the three launches */
+void lkgd_debug_set_gn_small_limits(int64_t total_bytes);   /* tensor size up to which the one-launch form is taken */
 
 #ifdef __cplusplus
 }

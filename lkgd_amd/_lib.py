@@ -120,6 +120,8 @@ SYMBOLS = {
     "lkgd_debug_set_gn_apply_kb": (None, [_i32]),
     "lkgd_debug_set_gn_stats_kb": (None, [_i32]),
     "lkgd_debug_set_gn_target_wgs": (None, [_i32]),
+    "lkgd_debug_set_gn_small": (None, [_i32]),
+    "lkgd_debug_set_gn_small_limits": (None, [_i64]),
 }
 
 _lib = None
@@ -142,7 +144,8 @@ def lib() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         if os.environ.get("LKGD_ATTN_PIPE"):     # A/B measurements only (same-box bench pairs): 1 = never the software-pipelined
             l.lkgd_debug_set_attn_pipe(int(os.environ["LKGD_ATTN_PIPE"]))   # attention program, 2 = wherever legal
-        for env, fn in (("LKGD_GN_TARGET_WGS", "lkgd_debug_set_gn_target_wgs"), ("LKGD_GEMM_VARIANT", "lkgd_debug_set_gemm_variant")):
+        for env, fn in (("LKGD_GN_TARGET_WGS", "lkgd_debug_set_gn_target_wgs"), ("LKGD_GEMM_VARIANT", "lkgd_debug_set_gemm_variant"),
+                        ("LKGD_GN_SMALL", "lkgd_debug_set_gn_small")):
             if os.environ.get(env):              # A/B measurements only
                 getattr(l, fn)(int(os.environ[env]))
         _lib = l

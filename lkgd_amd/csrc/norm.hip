@@ -442,12 +442,138 @@ extern "C" int lkgd_groupnorm_apply_segments(const void* segs, int32_t nseg, int
   return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
 }
 
-// The whole GroupNorm (+ SiLU) of a tensor in one C call: statistics pass, finalize, apply pass (three launches; what a
-// caller saves is two trips through its own call layer)
+// ---- small samples: the WHOLE GroupNorm (+ SiLU) in one launch.  One workgroup per (sample, group) holds its group's values
+// (rows x C/32 channels) in LDS: read once (fp16 -> LDS, fp32 sums on the way), reduce, normalise out of LDS, write.  For the
+// 18x32 / 9x16 levels (46 / 12 KiB per group) and the 36x64 level of the spatial norms (92 KiB): three dependent launches of
+// 5-8 us each become one - what counts on a sharded rank, whose GroupNorms are launch-bound (22.9 us per call on a rank of
+// 8 for 0.57 ms of bytes; profiles/r05_plan_profile_forms.txt).  VEC = halfs per access (C/32 = 40, 80 -> 8; 20, 60 -> 4;
+// 10, 30 -> 2): the group's channels of a row are contiguous, the thread -> element map and the reduction tree are fixed
+// (bitwise reproducible), the variance is E[x^2] - mean^2 in fp64 like gn_finalize_kernel's.
+#define GN_SMALL_NT 512
+#define GN_SMALL_U 4           // loads in flight per thread (one per iteration leaves a workgroup at 4 GB/s: 48 us for 90 KiB)
+template <int VEC>
+__global__ __launch_bounds__(GN_SMALL_NT) void gn_small_kernel(const half_t* x0, int c0, int ld0, const half_t* x1, int c1, int ld1,
+                                                               int rows, float eps, const float* gamma, const float* beta, int silu,
+                                                               half_t* out, int ldo, float* stats) {
+  typedef half_t hv_t __attribute__((ext_vector_type(VEC)));
+  extern __shared__ __attribute__((aligned(16))) char gn_smem[];
+  hv_t* buf = (hv_t*)gn_smem;
+  __shared__ double red[2 * (GN_SMALL_NT / 64)];
+  __shared__ float mr[2];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int g = blockIdx.x;
+  const long long sample = blockIdx.y;
+  const int gs = (c0 + c1) / GN_GROUPS, per = gs / VEC;           // channels per group, accesses per row
+  const int units = rows * per;
+  const long long base = sample * rows;
+  // element u = (row u / per, access u % per): stepped without divisions (NT = q * per + rem)
+  const int q = GN_SMALL_NT / per, rem = GN_SMALL_NT - q * per;
+  int r = t / per, a = t - r * per;
+  float s = 0.f, ss = 0.f;
+  for (int u = t; u < units; u += GN_SMALL_NT * GN_SMALL_U) {
+    hv_t v[GN_SMALL_U];
+#pragma unroll
+    for (int k = 0; k < GN_SMALL_U; ++k) {
+      const int c = g * gs + a * VEC;
+      const bool ok = u + k * GN_SMALL_NT < units;
+      const long long row = ok ? base + r : base;                  // (past the end: re-read row 0, never used)
+      const half_t* src = c < c0 ? x0 + row * ld0 + c : x1 + row * ld1 + (c - c0);
+      v[k] = *(const hv_t*)src;
+      r += q; a += rem;
+      if (a >= per) { a -= per; ++r; }
+    }
+#pragma unroll
+    for (int k = 0; k < GN_SMALL_U; ++k) {
+      if (u + k * GN_SMALL_NT < units) {
+        buf[u + k * GN_SMALL_NT] = v[k];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float f = (float)v[k][e]; s += f; ss += f * f; }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  if (lane == 0) { red[w] = (double)s; red[GN_SMALL_NT / 64 + w] = (double)ss; }
+  __syncthreads();
+  if (t == 0) {
+    const double inv = 1.0 / ((double)rows * (double)gs);
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int i = 0; i < GN_SMALL_NT / 64; ++i) { sa += red[i]; sb += red[GN_SMALL_NT / 64 + i]; }
+    const double mean = sa * inv;
+    double var = sb * inv - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[0] = (float)mean;
+    mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (stats) { stats[(sample * GN_GROUPS + g) * 2] = mr[0]; stats[(sample * GN_GROUPS + g) * 2 + 1] = mr[1]; }
+  }
+  __syncthreads();
+  const float mean = mr[0], rstd = mr[1];
+  r = t / per; a = t - r * per;
+  for (int u = t; u < units; u += GN_SMALL_NT) {
+    const int c = g * gs + a * VEC;
+    const hv_t v = buf[u];
+    hv_t o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float A = rstd * gamma[c + e], B = beta[c + e] - mean * A;       // (the same A, B as gn_apply_kernel)
+      float f = (float)v[e] * A + B;
+      if (silu) f = silu_f(f);
+      o[e] = (half_t)f;
+    }
+    *(hv_t*)(out + (base + r) * ldo + c) = o;
+    r += q; a += rem;
+    if (a >= per) { a -= per; ++r; }
+  }
+}
+
+static int gn_small_on = 1;                 // A/B knob: 0 = always the three launches
+extern "C" void lkgd_debug_set_gn_small(int on) { gn_small_on = on != 0; }
+#define GN_SMALL_LDS (48 * 1024)
+static long long gn_small_max_bytes = 10LL * 1024 * 1024 + 512 * 1024;
+extern "C" void lkgd_debug_set_gn_small_limits(int64_t total_bytes) { gn_small_max_bytes = total_bytes; }
+// does the one-launch form apply?  A workgroup reads its group as C/32-channel pieces of every row (20-160 bytes of each
+// 128-byte line: ~1.3 TB/s chip-wide against the chunked passes' whole rows), so it pays only while the launch overheads of
+// the three passes outweigh that: groups up to 48 KiB AND tensors up to 10.5 MB (tools/micro/gn_small.py, profiles/
+// r05_gn_small.txt: 4 x 576 x 1280 14.1 vs 18.1 us, 28 x 144 x 1280 15.1 vs 18.0, 4 x 144 x 2560 13.1 vs 22.4; beyond -
+// 14 x 576 x 1280 27.2 vs 22.5, 4 x 576 x 1920 22.8 vs 18.6 - the three launches win); at least 64 (sample, group) pairs
+static int gn_small_vec(int c0, int c1, int ld0, int ld1, int ldo, long long nsamples, long long rows, const void* out) {
+  const int C = c0 + c1, gs = C / GN_GROUPS;
+  if (!gn_small_on || rows * gs * 2 > GN_SMALL_LDS || nsamples * rows * C * 2 > gn_small_max_bytes || nsamples * GN_GROUPS < 64)
+    return 0;
+  const int vec = gs % 8 == 0 ? 8 : (gs % 4 == 0 ? 4 : (gs % 2 == 0 ? 2 : 0));
+  if (!vec || gs / vec > GN_SMALL_NT || c0 % vec || ld0 % vec || (c1 > 0 && ld1 % vec) || ldo % vec) return 0;
+  if (((uintptr_t)out) % (2 * vec)) return 0;
+  return vec;
+}
+
+// The whole GroupNorm (+ SiLU) of a tensor in one C call: one launch where a (sample, group) fits a workgroup's LDS
+// (gn_small_kernel), else statistics pass, finalize, apply pass (three launches; what a caller saves there is two trips
+// through its own call layer)
 extern "C" int lkgd_groupnorm_silu(const void* x0, int32_t c0, int32_t ld0, const void* x1, int32_t c1, int32_t ld1,
                                    int64_t nsamples, int64_t rows_per_sample, float eps, float* partial, float* stats,
                                    const float* gamma, const float* beta, int32_t silu, void* out, int32_t ldo,
                                    lkgd_stream_t stream) {
+  const int vec = gn_small_vec(c0, c1, ld0, ld1, ldo, nsamples, rows_per_sample, out);
+  if (vec) {
+    int rc = gn_check(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample);
+    if (rc) return rc;
+    if (!gamma || !beta || !out) return LKGD_E_NULL;
+    LKGD_DEVICE_ONCE_BEGIN
+      if (hipFuncSetAttribute((const void*)gn_small_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GN_SMALL_LDS) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gn_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GN_SMALL_LDS) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gn_small_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GN_SMALL_LDS) != hipSuccess)
+        return LKGD_E_LAUNCH;
+    LKGD_DEVICE_ONCE_END
+    const size_t lds = (size_t)rows_per_sample * ((c0 + c1) / GN_GROUPS) * 2;
+    const dim3 grid(GN_GROUPS, (unsigned)nsamples);
+#define GN_SMALL_GO(V)                                                                                                   \
+  hipLaunchKernelGGL(gn_small_kernel<V>, grid, dim3(GN_SMALL_NT), lds, (hipStream_t)stream, (const half_t*)x0, c0, ld0,          \
+                     (const half_t*)x1, c1, ld1, (int)rows_per_sample, eps, gamma, beta, silu, (half_t*)out, ldo, stats)
+    if (vec == 8) GN_SMALL_GO(8); else if (vec == 4) GN_SMALL_GO(4); else GN_SMALL_GO(2);
+#undef GN_SMALL_GO
+    return hipGetLastError() == hipSuccess ? LKGD_OK : LKGD_E_LAUNCH;
+  }
   int rc = lkgd_groupnorm_stats(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample, eps, partial, stats, stream);
   if (rc) return rc;
   return lkgd_groupnorm_apply(x0, c0, ld0, x1, c1, ld1, nsamples, rows_per_sample, stats, gamma, beta, silu, out, ldo, stream);

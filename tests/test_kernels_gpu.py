@@ -270,20 +270,58 @@ def test_groupnorm_silu(ops, C0, C1, rows, ns):
 def test_groupnorm_one_call_equals_three_launches_bitwise(C0, C1, rows, ns):
     """lkgd_groupnorm_silu against lkgd_groupnorm_stats + lkgd_groupnorm_apply on the maps of a frame-sharded rank (chunks cut
     down to 8 KiB so that small maps still fill the CUs) and of the full forward: the same bits, within tolerance of F.group_norm"""
-    from lkgd_amd import ops
+    from lkgd_amd import _lib, ops
     g = torch.Generator().manual_seed(C0 + C1 + rows)
     C = C0 + C1
     x = _h(torch.randn(ns * rows, C, generator=g) * 2 + 0.5)
     gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
     xd = x.to(DEV)
     x0, x1 = (xd[:, :C0], xd[:, C0:]) if C1 else (xd, None)
-    one = ops.groupnorm_silu(x0, x1, ns, rows, gamma, beta, 1e-5)
+    _lib.lib().lkgd_debug_set_gn_small(0)          # (small samples take ONE launch by default: the test below)
+    try:
+        one = ops.groupnorm_silu(x0, x1, ns, rows, gamma, beta, 1e-5)
+    finally:
+        _lib.lib().lkgd_debug_set_gn_small(1)
     stats = ops.groupnorm_stats(x0, x1, ns, rows, 1e-5)
     three = ops.groupnorm_apply(x0, x1, ns, rows, stats, gamma, beta, True, torch.empty_like(one))
     assert torch.equal(one, three)
     sub = slice(0, min(ns * rows, 20000))
     ref = F.silu(F.group_norm(x.float().reshape(ns, rows, C).permute(0, 2, 1), 32, gamma.cpu(), beta.cpu(), 1e-5))
     _close(one[sub], ref.permute(0, 2, 1).reshape(ns * rows, C)[sub], what="one-call groupnorm")
+
+
+@pytest.mark.parametrize("C0,C1,rows,ns,silu", [(1280, 0, 576, 4, True), (1280, 640, 384, 3, True), (640, 0, 1152, 4, True),
+                                                (320, 0, 144, 2, False), (1280, 1280, 144, 28, True), (640, 320, 100, 2, True),
+                                                (128, 192, 77, 2, True)])
+def test_groupnorm_one_launch_for_small_samples(C0, C1, rows, ns, silu):
+    """gn_small_kernel (one workgroup per (sample, group), the group's values held in LDS): every access width (C/32 = 40 / 80:
+    16 bytes, 20 / 60: 8, 10 / 30: 4), groups that straddle the two sources of a concatenated input, groups of 45 KiB - against the three launches (same arithmetic, another summation order of the statistics) and F.group_norm;
+    its (mean, rstd) output; a strided destination"""
+    from lkgd_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(C0 + 3 * C1 + rows)
+    C = C0 + C1
+    x = _h(torch.randn(ns * rows, C, generator=g) * 2 + 0.5)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    xd = x.to(DEV)
+    x0, x1 = (xd[:, :C0], xd[:, C0:]) if C1 else (xd, None)
+    wide = torch.full((ns * rows, C + 64), -7.0, dtype=torch.float16, device=DEV)
+    L.lkgd_debug_set_gn_small_limits(1 << 40)      # (the size rule would send the larger tensors to the three launches)
+    try:
+        one = ops.groupnorm_silu(x0, x1, ns, rows, gamma, beta, 1e-5, silu=silu, out=wide[:, 32:32 + C])
+    finally:
+        L.lkgd_debug_set_gn_small_limits(10 * 1024 * 1024 + 512 * 1024)
+    L.lkgd_debug_set_gn_small(0)
+    try:
+        three = ops.groupnorm_silu(x0, x1, ns, rows, gamma, beta, 1e-5, silu=silu)
+    finally:
+        L.lkgd_debug_set_gn_small(1)
+    assert (wide[:, :32] == -7).all() and (wide[:, 32 + C:] == -7).all()
+    d = (one.float() - three.float()).abs()
+    assert d.max().item() <= 4e-3 * three.float().abs().max().item() + 2e-3 and (d > 0).float().mean().item() < 0.05
+    ref = F.group_norm(x.float().reshape(ns, rows, C).permute(0, 2, 1), 32, gamma.cpu(), beta.cpu(), 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(ns * rows, C)
+    _close(one, ref, what="one-launch groupnorm")
 
 
 def test_groupnorm_apply_segments_equals_apply_bitwise():
