@@ -477,6 +477,7 @@ def main():
     events = [] if not args.no_kernel_events else None
     clips_sampled = 0
     barrier()
+    torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
     for c in range(args.steps):
         sample = events is not None and c % EVENT_CLIP_STRIDE == 0
@@ -492,6 +493,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     finite = bool(torch.isfinite(out.float()).all().item())
+    # working set of the timed region: live tensors at the peak (weights, packed weights, the forward's
+    # activations, bench inputs), what the caching allocator holds for them, and the recorded forward's private pool alone
+    owner = runner if distributed else pipe
+    memory = {"peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
+              "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 1e9, 2),
+              "plan_arena_gb": round(owner._arenas.reserved_bytes() / 1e9, 2)}
 
     roofline = None
     if events:
@@ -547,7 +554,7 @@ def main():
                                    + (" [TINY UNET - INVALID]" if args.tiny else ""),
                        "unet": "random-init SVD shapes (320,640,1280,1280), heads (5,10,20,20), 1.52 B params",
                        "parallelism": "single GPU" if world == 1 else f"cfg x frame shards over {world} GPUs"},
-            "finite_output": finite, "rccl_ranks": comm_ranks, "end_to_end": e2e,
+            "finite_output": finite, "rccl_ranks": comm_ranks, "memory": memory, "end_to_end": e2e,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

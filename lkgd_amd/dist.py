@@ -28,7 +28,9 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
+import math
 import os
+
 import torch
 import torch.distributed as dist
 
@@ -106,17 +108,29 @@ def all_gather_into(buf: torch.Tensor, send: torch.Tensor, group=None) -> None:
 
 def _step(f) -> None:
     """run a host-side exchange step now; under lkgd_amd.replay recording also make it part of the plan"""
-    from . import ops
-    f()
-    if ops.PLAN is not None:
-        ops.PLAN.python(f)
+    from . import replay
+    replay.step(f)
 
 
-def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+def _dest(out: Optional[torch.Tensor], shape, like: torch.Tensor) -> torch.Tensor:
+    """the caller's destination (a contiguous slice of a larger result: several batch entries per rank) or a new tensor"""
+    if out is None:
+        return torch.empty(shape, dtype=like.dtype, device=like.device)
+    if out.numel() != math.prod(shape) or not out.is_contiguous() or out.dtype != like.dtype or out.device != like.device:
+        raise ValueError("out= must be a contiguous tensor of the result's size, dtype and device")
+    return out.view(shape)
+
+
+def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """local [f_local, ...] -> [num_frames, ...] over the frame group (padded equal-count all-gather + compaction).
-    Buffers are allocated outside the replayable steps, so a recorded plan re-runs only copies and the collective."""
+    Buffers are allocated outside the replayable steps, so a recorded plan re-runs only copies and the collective.
+    ``out``: write the result there (every exchange step of a recorded plan then refreshes the caller's tensor itself)."""
     if plan.frame_shards == 1:
-        return local
+        if out is None:
+            return local
+        dst = _dest(out, tuple(local.shape), local)
+        _step(lambda: dst.copy_(local))
+        return dst
     fmax = plan.f_max
     if local.shape[0] != plan.f_local:
         raise ValueError("local frame count does not match the plan")
@@ -127,11 +141,12 @@ def gather_frames(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Ten
         send = torch.zeros((fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         head = send[:plan.f_local]
         _step(lambda: head.copy_(local))
-    buf = torch.empty((plan.frame_shards * fmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    even = all(s == fmax for s in plan.splits)
+    buf = _dest(out if even else None, (plan.frame_shards * fmax,) + tuple(local.shape[1:]), local)
     _step(lambda: all_gather_into(buf, send, group))
-    if all(s == fmax for s in plan.splits):
+    if even:
         return buf
-    out = torch.empty((plan.num_frames,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out = _dest(out, (plan.num_frames,) + tuple(local.shape[1:]), local)
     pairs, f = [], 0
     for j, n in enumerate(plan.splits):
         pairs.append((out[f:f + n], buf[j * fmax:j * fmax + n]))
@@ -175,20 +190,24 @@ def all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_rows: List[int], i
     out.copy_(ho)
 
 
-def frames_to_pixels(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+def frames_to_pixels(local: torch.Tensor, plan: ShardPlan, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """local [f_local, HW, C] (this rank's frames, all pixels) -> [F, px_local, C] (all frames, this rank's pixel slice)
     over the frame group.  Peer r gets this rank's frames of ITS pixel range and sends its frames of ours; the received
     blocks arrive in rank = frame order, so the result is frame-major without a compaction."""
     k, si = plan.frame_shards, plan.shard_index
     if k == 1:
-        return local
+        if out is None:
+            return local
+        dst = _dest(out, tuple(local.shape), local)
+        _step(lambda: dst.copy_(local))
+        return dst
     fl, HW, C = local.shape
     if fl != plan.f_local or not local.is_contiguous():
         raise ValueError("frames_to_pixels needs this rank's contiguous [f_local, HW, C] slice")
     px = pixel_splits(HW, k)
     p0 = [sum(px[:r]) for r in range(k)]
     send = torch.empty(fl * HW, C, dtype=local.dtype, device=local.device)
-    recv = torch.empty(plan.num_frames * px[si], C, dtype=local.dtype, device=local.device)
+    recv = _dest(out, (plan.num_frames * px[si], C), local)
     in_rows = [fl * px[r] for r in range(k)]
     out_rows = [plan.splits[r] * px[si] for r in range(k)]
     pieces, o = [], 0
@@ -210,11 +229,15 @@ def frames_to_pixels(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.
     return recv.view(plan.num_frames, px[si], C)
 
 
-def pixels_to_frames(x: torch.Tensor, plan: ShardPlan, HW: int, group=None) -> torch.Tensor:
+def pixels_to_frames(x: torch.Tensor, plan: ShardPlan, HW: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """inverse of frames_to_pixels: x [F, px_local, C] -> [f_local, HW, C]"""
     k, si = plan.frame_shards, plan.shard_index
     if k == 1:
-        return x
+        if out is None:
+            return x
+        dst = _dest(out, tuple(x.shape), x)
+        _step(lambda: dst.copy_(x))
+        return dst
     F, pl, C = x.shape
     px = pixel_splits(HW, k)
     if F != plan.num_frames or pl != px[si] or not x.is_contiguous():
@@ -222,7 +245,7 @@ def pixels_to_frames(x: torch.Tensor, plan: ShardPlan, HW: int, group=None) -> t
     fl = plan.f_local
     p0 = [sum(px[:r]) for r in range(k)]
     recv = torch.empty(fl * HW, C, dtype=x.dtype, device=x.device)
-    out = torch.empty(fl, HW, C, dtype=x.dtype, device=x.device)
+    out = _dest(out, (fl, HW, C), x)
     in_rows = [plan.splits[r] * pl for r in range(k)]          # frames of shard r are contiguous rows of x
     out_rows = [fl * px[r] for r in range(k)]
     pieces, o = [], 0

@@ -50,35 +50,50 @@ class ShardInfo:
         self.B_total = self.plan.cfg_groups * entries      # batch entries of the whole job
         self.b0 = self.plan.cfg_index * entries            # first global batch entry of this rank
 
-    def _per_entry(self, x: torch.Tensor, f):
-        """apply f to each entry's contiguous row block and stack the results"""
+    def _per_entry(self, x: torch.Tensor, f, rows_out: int):
+        """apply f(entry rows, out=) to each entry's contiguous row block; ``rows_out`` result rows per entry.  The result tensor is
+        allocated ONCE and every entry's exchange writes its own slice of it: under lkgd_amd.replay the exchanges are the steps
+        a plan re-runs, so nothing that is not such a step (a torch.cat of the parts) may stand between them and
+        the kernels that read the result through recorded pointers."""
         n = self.entries
+        if self.plan.frame_shards == 1:
+            return x                          # one frame slice: nothing to exchange
         if n == 1:
-            return f(x)
+            return f(x, None)
         rows = x.shape[0] // n
-        return torch.cat([f(x[e * rows:(e + 1) * rows]) for e in range(n)])
+        out = torch.empty(n * rows_out, x.shape[-1], dtype=x.dtype, device=x.device)
+        for e in range(n):
+            f(x[e * rows:(e + 1) * rows], out[e * rows_out:(e + 1) * rows_out])
+        return out
 
     def gather(self, local: torch.Tensor) -> torch.Tensor:
         """[entries*f_local*HW, C] tokens -> [entries*F*HW, C] over the frame group"""
         fl = self.plan.f_local
+        hw = local.shape[0] // (self.entries * fl)
 
-        def one(t):
-            return gather_frames(t.reshape(fl, -1, t.shape[-1]), self.plan, self.group).reshape(-1, t.shape[-1])
-        return self._per_entry(local, one)
+        def one(t, out):
+            return gather_frames(t.reshape(fl, -1, t.shape[-1]), self.plan, self.group, out=out).reshape(-1, t.shape[-1])
+        return self._per_entry(local, one, self.plan.num_frames * hw)
 
     def to_pixels(self, local: torch.Tensor, HW: int) -> torch.Tensor:
         """[entries*f_local*HW, C] tokens (own frames, all pixels) -> [entries*F*px_local, C] (all frames, own pixel slice): all-to-all"""
-        def one(t):
-            return frames_to_pixels(t.reshape(self.plan.f_local, HW, t.shape[-1]), self.plan, self.group).reshape(-1, t.shape[-1])
-        return self._per_entry(local, one)
+        from .dist import pixel_splits
+        k = self.plan.frame_shards
+        pxl = pixel_splits(HW, k)[self.plan.shard_index] if k > 1 else HW
+
+        def one(t, out):
+            return frames_to_pixels(t.reshape(self.plan.f_local, HW, t.shape[-1]), self.plan, self.group,
+                                    out=out).reshape(-1, t.shape[-1])
+        return self._per_entry(local, one, self.plan.num_frames * pxl)
 
     def to_frames(self, x: torch.Tensor, HW: int) -> torch.Tensor:
         """inverse of to_pixels"""
         F = self.plan.num_frames
 
-        def one(t):
-            return pixels_to_frames(t.reshape(F, t.shape[0] // F, t.shape[-1]), self.plan, HW, self.group).reshape(-1, t.shape[-1])
-        return self._per_entry(x, one)
+        def one(t, out):
+            return pixels_to_frames(t.reshape(F, t.shape[0] // F, t.shape[-1]), self.plan, HW, self.group,
+                                    out=out).reshape(-1, t.shape[-1])
+        return self._per_entry(x, one, self.plan.f_local * HW)
 
     def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
         return allreduce_sums(sums, self.plan, self.group)
@@ -114,6 +129,7 @@ class DistDenoiser:
         #: replay the step's UNet forward from a recorded launch list (lkgd_amd/replay.py); a frame-sharded rank has
         #: only ~1/8 of the device work per forward and would otherwise wait on the Python module walk
         self.use_replay = os.environ.get("LKGD_NO_REPLAY", "0") != "1"
+        self._arenas = replay.ArenaSet()          # the recorded forward's private allocator pool (lkgd_amd/replay.py)
         #: bench.py's per-launch GEMM events (ops.GEMM_EVENTS) are taken on every `event_stride`-th Euler step only: an
         #: event pair per launch is ~600 extra queue packets per forward, which a rank with ~24 ms of device work per
         #: forward would feel (on one GPU every step is sampled)
@@ -199,35 +215,37 @@ class DistDenoiser:
             return unet.forward_tokens(tok_local, b_local, fl, H, W, t_dev, enc, ids_local, down, mid, shard=self.shard)[0]
         recorded = None
         events_all = ops.GEMM_EVENTS
-        for i, t in enumerate(sch.timesteps_host):
-            sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
-            ops.GEMM_EVENTS = events_all if (events_all is not None and i % self.event_stride == self.event_stride // 2) else None
-            ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=tok)     # [cfg*F*HW, 8], replicated
-            if pick is not None:
-                pick[0].copy_(pick[1])
-            t_dev.fill_(float(t))
+        try:
+            for i, t in enumerate(sch.timesteps_host):
+                sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
+                ops.GEMM_EVENTS = events_all if (events_all is not None and i % self.event_stride == self.event_stride // 2) else None
+                ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=tok)     # [cfg*F*HW, 8], replicated
+                if pick is not None:
+                    pick[0].copy_(pick[1])
+                t_dev.fill_(float(t))
+                if recorded is not None:
+                    noise_local = recorded.run(ops.GEMM_EVENTS)
+                elif self.use_replay:
+                    with replay.record(self._arenas.take(dev)) as recorded:   # the first step runs for real and is recorded
+                        recorded.result = forward()
+                    noise_local = recorded.result
+                else:
+                    noise_local = forward()
+                # ---- exchange the noise prediction over all ranks (padded equal counts), compact, replicate the update
+                send[:, :fl * HW].copy_(noise_local.reshape(b_local, fl * HW, 4))
+                all_gather_into(buf.reshape(-1, 4), send.reshape(-1, 4))
+                nf = noise_full.reshape(cfg * B, F * HW, 4)
+                for r in range(plan.world):
+                    ci, si = divmod(r, plan.frame_shards)
+                    n, fs = plan.splits[si], sum(plan.splits[:si])
+                    er = ci * b_local if plan.cfg_groups == 2 else 0
+                    nf[er:er + b_local, fs * HW:(fs + n) * HW].copy_(buf[r, :, :n * HW])
+                ops.cfg_euler_step(noise_full, latents, guidance, cfg, sigma, sigma_next, v_prediction=vpred)
+        finally:          # whatever ended the loop: the bench's event list is restored, the plan's activations are freed
+            ops.GEMM_EVENTS = events_all
             if recorded is not None:
-                noise_local = recorded.run(ops.GEMM_EVENTS)
-            elif self.use_replay:
-                with replay.record() as recorded:           # the first step runs for real and is recorded
-                    recorded.result = forward()
-                noise_local = recorded.result
-            else:
-                noise_local = forward()
-            # ---- exchange the noise prediction over all ranks (padded equal counts), compact, replicate the update
-            send[:, :fl * HW].copy_(noise_local.reshape(b_local, fl * HW, 4))
-            all_gather_into(buf.reshape(-1, 4), send.reshape(-1, 4))
-            nf = noise_full.reshape(cfg * B, F * HW, 4)
-            for r in range(plan.world):
-                ci, si = divmod(r, plan.frame_shards)
-                n, fs = plan.splits[si], sum(plan.splits[:si])
-                er = ci * b_local if plan.cfg_groups == 2 else 0
-                nf[er:er + b_local, fs * HW:(fs + n) * HW].copy_(buf[r, :, :n * HW])
-            ops.cfg_euler_step(noise_full, latents, guidance, cfg, sigma, sigma_next, v_prediction=vpred)
-        ops.GEMM_EVENTS = events_all
+                recorded.release()
         sch._step_index = num_inference_steps
-        if recorded is not None:
-            recorded.release()
         return latents
 
 

@@ -169,6 +169,8 @@ def gemm(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
             buf = torch.empty((M + blk - 1) // blk, N // 2, 2, dtype=torch.float32, device=out.device)   # channel pairs
             d.colstats = buf.data_ptr()
             out._lkgd_colstats = (buf, blk, out._version)      # see _stats_from_cols: void once `out` is written again
+        else:
+            d.cs_rows = 0                # no sums attached: the tile-form choice is not restricted either
     ev = GEMM_EVENTS
     if ev is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -77,6 +77,9 @@ class StableVideoDiffusionPipeline:
         self._graph = None
         #: replay the step's forward from a recorded launch list (denoise(); LKGD_NO_REPLAY=1 = walk the modules every step)
         self.use_replay = __import__("os").environ.get("LKGD_NO_REPLAY", "0") != "1"
+        #: private allocator pools the recorded forwards allocate from (lkgd_amd/replay.py): the plan's working set is the eager
+        #: peak of one forward, and the blocks stay cached here between calls; ``release_arena()`` returns them to the driver
+        self._arenas = _replay.ArenaSet()
 
     # ---- loading (DiffusionPipeline.from_pretrained [EXT]; call sites run_models/run_inference_svd.py:166-168,
     #      utils/util.py:536) --------------------------------------------------------------------------------------
@@ -290,7 +293,6 @@ class StableVideoDiffusionPipeline:
             if ctrl is not None:
                 self.controlnet.prepare()
                 self.controlnet._cond_tokens(ctrl, cfg * B, F, H, W)       # once per clip, outside the recorded forward
-            recorded = None
 
             def forward_static():
                 down = mid = None
@@ -300,43 +302,56 @@ class StableVideoDiffusionPipeline:
                 return unet.forward_tokens(tok_buf, cfg * B, F, H, W, t_dev, enc_r, ids_r, down, mid)[0]
         timers = _trace.StepTimers() if _trace.STEP_TIMERS else None      # LKGD_STEP_TIMERS=1: device ms per Euler step
         self.last_step_timers = timers
-        for i, t in enumerate(sch.timesteps_host):
-            sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
-            _trace.push(f"euler_step_{i}")                                  # roctx range (LKGD_ROCTX=1), else a no-op
-            t_ev = timers.start() if timers is not None else None
-            if fwd is not None:
-                ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=fwd.tok)
-                noise_tok = fwd.run(t)
-            elif use_replay:
-                ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=tok_buf)
-                t_dev.fill_(float(t))
-                if recorded is not None:
-                    noise_tok = recorded.run(ops.GEMM_EVENTS)
+        recorded = None
+        try:
+            for i, t in enumerate(sch.timesteps_host):
+                sigma, sigma_next = sch.sigmas_host[i], sch.sigmas_host[i + 1]
+                _trace.push(f"euler_step_{i}")                                  # roctx range (LKGD_ROCTX=1), else a no-op
+                t_ev = timers.start() if timers is not None else None
+                if fwd is not None:
+                    ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=fwd.tok)
+                    noise_tok = fwd.run(t)
+                elif use_replay:
+                    ops.prepare_unet_input(latents, image_latents, cfg, sigma, out=tok_buf)
+                    t_dev.fill_(float(t))
+                    if recorded is not None:
+                        noise_tok = recorded.run(ops.GEMM_EVENTS)
+                    else:
+                        with _replay.record(self._arenas.take(dev)) as recorded:
+                            recorded.result = forward_static()
+                        noise_tok = recorded.result
                 else:
-                    with _replay.record() as recorded:
-                        recorded.result = forward_static()
-                    noise_tok = recorded.result
-            else:
-                tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)
-                down = mid = None
-                if ctrl is not None:      # residuals stay channels-last token matrices between the two models
-                    down, mid, _ = self.controlnet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids, ctrl,
-                                                                  controlnet_cond_scale)
-                noise_tok, _ = unet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids, down, mid)
-            ops.cfg_euler_step(noise_tok, latents, guidance_dev, cfg, sigma, sigma_next, v_prediction=vpred)
-            if timers is not None:
-                timers.stop(t_ev)
-            _trace.pop()
-            if callback_on_step_end is not None:
-                kw = {k: {"latents": latents}[k] for k in callback_on_step_end_tensor_inputs}
-                out = callback_on_step_end(self, i, t, kw)
-                latents = out.pop("latents", latents) if isinstance(out, dict) else latents
+                    tok = ops.prepare_unet_input(latents, image_latents, cfg, sigma)
+                    down = mid = None
+                    if ctrl is not None:      # residuals stay channels-last token matrices between the two models
+                        down, mid, _ = self.controlnet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids, ctrl,
+                                                                      controlnet_cond_scale)
+                    noise_tok, _ = unet.forward_tokens(tok, cfg * B, F, H, W, t, enc, ids, down, mid)
+                ops.cfg_euler_step(noise_tok, latents, guidance_dev, cfg, sigma, sigma_next, v_prediction=vpred)
+                if timers is not None:
+                    timers.stop(t_ev)
+                _trace.pop()
+                if callback_on_step_end is not None:
+                    kw = {k: {"latents": latents}[k] for k in callback_on_step_end_tensor_inputs}
+                    out = callback_on_step_end(self, i, t, kw)
+                    latents = out.pop("latents", latents) if isinstance(out, dict) else latents
+        finally:
+            # the recorded forward's activations go back to the allocator whatever ended the loop (a callback's exception, a
+            # launch error, KeyboardInterrupt): the plan and its recording stand-in reference each other
+            if recorded is not None:
+                recorded.release()
         sch._step_index = num_inference_steps
         if timers is not None:
             timers.finish()
-        if use_replay and recorded is not None:
-            recorded.release()          # the recorded forward's activations (tens of GB at full size) go back to the allocator
         return latents
+
+    def release_arena(self) -> None:
+        """return the recorded forwards' working-set pool(s) to the driver (they are kept between calls otherwise)"""
+        self._arenas.clear()
+
+    def arena_reserved_bytes(self) -> int:
+        """device memory the recorded forward's private pool holds (the plan's working set)"""
+        return self._arenas.reserved_bytes()
 
     def _latents_for_decode(self, latents: torch.Tensor) -> torch.Tensor:
         """hook between the loop and the VAE decode (identity here; the flow pipeline un-normalises)"""
@@ -499,6 +514,14 @@ class StableVideoDiffusionPipelineControlNetFlow(StableVideoDiffusionPipelineCon
 
     def _condition(self, controlnet_condition):
         return None
+
+    def release_arena(self) -> None:
+        """return the recorded forwards' working-set pool(s) to the driver (they are kept between calls otherwise)"""
+        self._arenas.clear()
+
+    def arena_reserved_bytes(self) -> int:
+        """device memory the recorded forward's private pool holds (the plan's working set)"""
+        return self._arenas.reserved_bytes()
 
     def _latents_for_decode(self, latents: torch.Tensor) -> torch.Tensor:
         from .optical_flow import optical_flow_latent_unnormalize

@@ -884,28 +884,33 @@ class SpatioTemporalResBlock(nn.Module):
             n, W = HW * Cc, 2 * HW * Cc + _dist.SUMS_SLOT
             parts = got.view(-1)[2 * n:].view(torch.float32)              # rank 0 / entry 0's sums; strides in floats below
             stats = ops.groupnorm_finalize_parts(parts, k, ctx.B * W // 2, ctx.B, W // 2, count, eps)
-            segs = []             # one launch: own frames of every entry + the neighbours' raw boundary frames
+            segs, pads = [], []   # one launch: own frames of every entry + the neighbours' raw boundary frames
             for b in range(ctx.B):
                 segs.append((x[b * rows:(b + 1) * rows], buf[b * blk + HW:(b + 1) * blk - HW], b))
                 if si == 0:
-                    buf[b * blk:b * blk + HW].zero_()
+                    pads.append(buf[b * blk:b * blk + HW])
                 else:             # the previous shard's LAST frame
                     segs.append((got[si - 1, b, n:2 * n].view(HW, Cc), buf[b * blk:b * blk + HW], b))
                 if si == k - 1:
-                    buf[(b + 1) * blk - HW:(b + 1) * blk].zero_()
+                    pads.append(buf[(b + 1) * blk - HW:(b + 1) * blk])
                 else:             # the next shard's FIRST frame
                     segs.append((got[si + 1, b, :n].view(HW, Cc), buf[(b + 1) * blk - HW:(b + 1) * blk], b))
+            if pads:              # the clip's end slots = the Conv3d's zero padding; a replayed step: buf is scratch of the plan
+                _dist._step(lambda: [p.zero_() for p in pads])
             ops.groupnorm_apply_segments(segs, stats, *affine, True)
             return buf
         sums = ctx.shard.allreduce(ops.groupnorm_sums(x, None, ctx.B, rows))
         stats = ops.groupnorm_finalize(sums, count, eps)
+        pads = []
         for b in range(ctx.B):
             if plan.shard_index == 0:
-                buf[b * blk:b * blk + ctx.HW].zero_()
+                pads.append(buf[b * blk:b * blk + ctx.HW])
             if plan.shard_index == plan.frame_shards - 1:
-                buf[(b + 1) * blk - ctx.HW:(b + 1) * blk].zero_()
+                pads.append(buf[(b + 1) * blk - ctx.HW:(b + 1) * blk])
             ops.groupnorm_apply(x[b * rows:(b + 1) * rows], None, 1, rows, stats[b:b + 1], *affine, True,
                                 buf[b * blk + ctx.HW:(b + 1) * blk - ctx.HW])
+        if pads:
+            _dist._step(lambda: [p.zero_() for p in pads])
         return ctx.shard.halo(buf)
 
 

@@ -216,3 +216,54 @@ def test_thread_world_collectives_match_their_definitions():
         want = torch.cat([(torch.arange(14, dtype=torch.float32).reshape(7, 2) + 100 * (base + p))[start:start + rows[si]]
                           for p in range(4)])
         assert torch.equal(out, want)
+
+
+def _worker_replay_entries(rank, world, port, frames, q):
+    """with several batch entries per rank the joined result of the per-entry exchanges must be refreshed by
+    the recorded steps themselves - record, change the inputs in place, replay, compare"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkgd_amd import replay
+        from lkgd_amd.dist import pixel_splits
+        from lkgd_amd.dist_run import ShardInfo
+        plan = make_plan(world, rank, frames, cfg=False)
+        ok = True
+        for entries in (1, 2, 3):
+            sh = ShardInfo(plan, None, entries=entries)
+            HW, C = 8, 3
+            both = torch.arange(entries * frames * HW * C, dtype=torch.float32).reshape(entries, frames, HW, C) + 1.0
+            mine = both[:, plan.f0:plan.f0 + plan.f_local].reshape(-1, C).clone()
+            px = pixel_splits(HW, world)
+            p0 = sum(px[:plan.shard_index])
+            with replay.record() as rec:
+                full = sh.gather(mine)
+                xp = sh.to_pixels(mine, HW)
+                back = sh.to_frames(xp, HW)
+            for scale in (1.0, -3.0, 0.5):
+                if scale != 1.0:
+                    mine.copy_(scale * both[:, plan.f0:plan.f0 + plan.f_local].reshape(-1, C))
+                    rec.run()
+                ok = ok and torch.equal(full, scale * both.reshape(-1, C))
+                ok = ok and torch.equal(xp, scale * both[:, :, p0:p0 + px[plan.shard_index]].reshape(-1, C))
+                ok = ok and torch.equal(back, mine)
+            rec.release()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames", [(2, 5), (4, 6)])
+def test_recorded_multi_entry_exchanges_follow_their_inputs(world, frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_replay_entries, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]
