@@ -173,7 +173,9 @@ class ControlNetSDVModel(_UNetBase):
         """channels-last entry: input tokens [B*F*H*W, 8] -> (list of 12 residual token matrices, mid residual tokens).
         Under frame / CFG sharding (``shard``, lkgd_amd/dist_run.py) B, F, the tokens and ``controlnet_cond`` are the
         rank's LOCAL batch entries / frames; the encoder's temporal ops exchange exactly as the UNet's do."""
-        self.prepare()
+        from . import replay as _replay
+        with _replay.invariant():
+            self.prepare()
         ctx = Ctx(B, F, H, W, self.device, shard)
         pk = self._pk
         if getattr(pk, "has_lora", False):

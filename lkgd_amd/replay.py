@@ -17,6 +17,12 @@ Contract of a recorded region
     contract - an in-place write to a device tensor, a new device tensor computed from device inputs - into errors unless they
     stand inside ``step`` or ``invariant()``.
 
+Why ONLY scratch goes to the pool: a constant made by a torch op in the middle of the region must not sit in memory that an
+EARLIER launch of the plan used as scratch - the eager pass is past that launch, a replay runs it again and would overwrite the
+constant (seen on the first try: the `torch.arange` feeding a later transformer's frame-position table landed in a block an
+earlier transformer's table computation had used and freed).  So the region routes exactly the ``torch.empty``-class calls to
+the arena and everything else to the ordinary allocator, where the plan keeps it alive.
+
 Working set (round 6; the reference's knobs for the same problem are ``enable_forward_chunking`` /
 ``decode_chunk_size``, models/unet_spatio_temporal_condition_controlnet.py:329-356, pipeline_stable_video_diffusion_trans.py:
 267-275).  Until round 5 the plan kept every tensor the region created alive (~55 GB for the headline clip: each of the ~1000
@@ -123,8 +129,13 @@ class Arena:
 
     @contextlib.contextmanager
     def allocating(self):
-        with torch.cuda.use_mem_pool(self.pool, self.device):
+        """this thread's allocations come from the pool inside (what torch.cuda.use_mem_pool does, per call)"""
+        torch._C._cuda_beginAllocateCurrentThreadToPool(self.device.index, self.pool.id)
+        try:
             yield
+        finally:
+            torch._C._cuda_endAllocateToPool(self.device.index, self.pool.id)
+            torch._C._cuda_releasePool(self.device.index, self.pool.id)      # the reference `begin` took; the MemPool keeps its own
 
     def reserved_bytes(self) -> int:
         pid = tuple(self.pool.id)
@@ -191,13 +202,17 @@ class _Region(TorchFunctionMode):
     """what torch calls mean inside a recorded region.  ``keep_all`` (no arena: the CPU tensors of the gloo tests) keeps every
     result alive, as rounds 2-5 did; with an arena only the results no launch regenerates are kept (module docstring)."""
 
-    def __init__(self, keep: list, keep_all: bool):
+    def __init__(self, keep: list, keep_all: bool, arena: Optional[Arena] = None):
         super().__init__()
-        self.keep, self.keep_all = keep, keep_all
+        self.keep, self.keep_all, self.arena = keep, keep_all, arena
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        out = func(*args, **kwargs)
+        if self.arena is not None and func in _SCRATCH:
+            with self.arena.allocating():
+                out = func(*args, **kwargs)
+        else:
+            out = func(*args, **kwargs)
         if self.keep_all:
             self.keep.append(out)
             if not STRICT:
@@ -319,8 +334,9 @@ class record:
     region allocates from its private pool and the plan holds only what replays do not regenerate; None: every tensor the
     region creates is kept alive (CPU tensors, or a caller that wants no pool)."""
 
-    def __init__(self, arena: Optional[Arena] = None):
+    def __init__(self, arena: Optional[Arena] = None, keep_all: Optional[bool] = None):
         self.arena = arena
+        self.keep_all = (arena is None) if keep_all is None else keep_all
 
     def __enter__(self) -> Plan:
         from . import ops
@@ -334,9 +350,7 @@ class record:
         ops.set_plan(self.plan)
         self.stack = contextlib.ExitStack()
         try:
-            if self.arena is not None:
-                self.stack.enter_context(self.arena.allocating())
-            self.stack.enter_context(_Region(self.plan.keep, keep_all=self.arena is None))
+            self.stack.enter_context(_Region(self.plan.keep, self.keep_all, self.arena))
         except BaseException:
             ops.set_plan(None)
             self.stack.close()

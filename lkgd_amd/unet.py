@@ -35,6 +35,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import replay as _replay
 from . import trace as _trace
 from ._lib import LkgdHipError
 from .packing import pack_conv3x3, pack_conv3x3_c8, pack_ff_fused, pack_geglu, pack_linear, pack_tconv3
@@ -247,9 +248,10 @@ def _attn_variant(block, which: str, ctx: "Ctx", run: int, spatial: bool):
            P.adapters(attn.to_out[0], run))
     v = pk.var.get(key)
     if v is None:
-        v = attn.pack_self(block.norm1, key[1:])
-        if jn:
-            _pack_joint_post(block, v, spatial, key[4])
+        with _replay.invariant():
+            v = attn.pack_self(block.norm1, key[1:])
+            if jn:
+                _pack_joint_post(block, v, spatial, key[4])
         pk.var[key] = v
     return v
 
@@ -351,7 +353,8 @@ def _cross_literal(block, ctx: Ctx, h1: torch.Tensor, rowmap, first_ctx: int) ->
     to_out + residual.  The one-token case never comes here (folded into a row bias by _cross_tables)."""
     pk = block._pk
     if not hasattr(pk, "x2"):
-        pk.x2 = block.attn2.pack_cross(block.norm2)
+        with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
+            pk.x2 = block.attn2.pack_cross(block.norm2)
     x2, (T, Cc), Lk = pk.x2, h1.shape, ctx.cross_Lk
     ln2 = ops.layernorm(h1, None, None, 1e-5)
     q = ctx.new(T, Cc)
@@ -413,7 +416,8 @@ class BasicTransformerBlock(nn.Module):
         if one:
             if getattr(pk.a1, "wlnqkv", None) is None:
                 from .packing import pack_ln_proj
-                pk.a1.wlnqkv = pack_ln_proj(pk.a1.wqkv, pk.a1.bqkv)
+                with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
+                    pk.a1.wlnqkv = pack_ln_proj(pk.a1.wqkv, pk.a1.bqkv)
             ops.ln_qkv(h, pk.a1.wlnqkv, qkv)
         elif fold:
             ops.gemm(h, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv, ln=(pk.a1.cs, 1e-5))
@@ -500,7 +504,8 @@ class BasicTransformerBlock(nn.Module):
         if ctx.N % 2:
             raise LkgdHipError("FSM hook: batch*frames must be even (hidden_states[::2] / [1::2] pairs)")
         from .patch_FSM import track_tables
-        fwd, bwd = track_tables(self, ctx)
+        with _replay.invariant():            # set once per clip (update_patch): constants of the clip's plan
+            fwd, bwd = track_tables(self, ctx)
         pairs, HW = ctx.N // 2, ctx.HW
         srcf, red = ctx.new(pairs * HW, Cc), ctx.new(pairs * HW, Cc)
         ops.fsm_rows(hA, srcf, pairs=pairs, HW=HW, C_=Cc, a_rows=(2 * HW, 0), o_rows=(HW, 0))
@@ -580,7 +585,8 @@ class TemporalBasicTransformerBlock(nn.Module):
         elif fused:
             if getattr(pk.a1, "wfront", None) is None:
                 from .packing import pack_tfront
-                pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
+                with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
+                    pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
             ops.tattn_front(m1, pk.a1.wfront, pk.a1.bqkv, att, ctx.B, ctx.F, ctx.HW, self.attn1.heads)
         elif ctx.lora is not None:
             if ctx.frames_sharded:
@@ -595,7 +601,8 @@ class TemporalBasicTransformerBlock(nn.Module):
             if ln_qkv_one:
                 if getattr(pk.a1, "wlnqkv", None) is None:
                     from .packing import pack_ln_proj
-                    pk.a1.wlnqkv = pack_ln_proj(pk.a1.wqkv, pk.a1.bqkv)
+                    with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
+                        pk.a1.wlnqkv = pack_ln_proj(pk.a1.wqkv, pk.a1.bqkv)
                 ops.ln_qkv(m1, pk.a1.wlnqkv, qkv)
             else:
                 ops.gemm(ln1, pk.a1.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
@@ -613,7 +620,8 @@ class TemporalBasicTransformerBlock(nn.Module):
             if ops.tattn_front_ok(Cc, self.attn1.heads, Ft, pxl):
                 if getattr(pk.a1, "wfront", None) is None:
                     from .packing import pack_tfront
-                    pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
+                    with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
+                        pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
                 ops.tattn_front(m1p, pk.a1.wfront, pk.a1.bqkv, attp, ctx.B, Ft, pxl, self.attn1.heads)
             else:
                 ln1p = ops.layernorm(m1p, None, None, 1e-5)
@@ -666,7 +674,8 @@ class TemporalBasicTransformerBlock(nn.Module):
         if one_launch:
             if getattr(pk.a1, "wblock", None) is None:
                 from .packing import pack_tblock
-                pk.a1.wblock = pack_tblock(pk.a1.wqkv, pk.a1.bqkv, pk.a1.wo, self.attn1.heads)
+                with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
+                    pk.a1.wblock = pack_tblock(pk.a1.wqkv, pk.a1.bqkv, pk.a1.wo, self.attn1.heads)
             ops.tattn_block(m1, pk.a1.wblock, pk.a1.bo, m2, ctx.B, ctx.F, ctx.HW, rowbias=xtab, rowmap=xmap)
         elif va is None:
             ops.gemm(att, pk.a1.wo, m2, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=m1, rowbias=xtab, rowmap=xmap)
@@ -759,7 +768,8 @@ class TransformerSpatioTemporalModel(nn.Module):
     def run(self, ctx: Ctx, x: torch.Tensor) -> torch.Tensor:
         pk, T, Cc = self._pk, x.shape[0], x.shape[1]
         if self._alpha is None:
-            self._alpha = float(torch.sigmoid(self.time_mixer.mix_factor.detach().float()).item())
+            with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
+                self._alpha = float(torch.sigmoid(self.time_mixer.mix_factor.detach().float()).item())
         n = ops.groupnorm_silu(x, None, ctx.N, ctx.HW, *pk.gn, 1e-6, silu=False)
         h = ctx.new(T, Cc)
         ops.gemm(n, pk.win, h, M=T, N=Cc, K=Cc, bias=pk.bin)
@@ -827,7 +837,8 @@ class SpatioTemporalResBlock(nn.Module):
         """x = cat(x0, x1) on channels (skip connection folded into the consumers' gathers)"""
         pk = self._pk
         if pk.alpha is None:
-            pk.alpha = float(torch.sigmoid(self.time_mixer.mix_factor.detach().float()).item())
+            with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
+                pk.alpha = float(torch.sigmoid(self.time_mixer.mix_factor.detach().float()).item())
         T, Cin, Cout = ctx.T, self.in_channels, self.out_channels
         c0 = x0.shape[1]
         bmap = ops.rowmap_div(ctx.F * ctx.HW)
@@ -1333,8 +1344,9 @@ class _UNetBase(nn.Module):
                 continue
             wx = pk.x_var.get(key)
             if wx is None:
-                wx = torch.cat([a.fold_cross(k)[0] for a, k in zip(self._cross_reg, key)], dim=0)
-                wx = pk.x_var[key] = wx.to(torch.float16).contiguous()
+                with _replay.invariant():
+                    wx = torch.cat([a.fold_cross(k)[0] for a, k in zip(self._cross_reg, key)], dim=0)
+                    wx = pk.x_var[key] = wx.to(torch.float16).contiguous()
             tab = torch.empty_like(ctx.xb_all)
             ops.gemm(e, wx, tab, M=Bt, N=wx.shape[0], K=wx.shape[1], bias=pk.b_x)
             ctx.xb_runs.append(tab)
@@ -1417,7 +1429,8 @@ class _UNetBase(nn.Module):
                        shard=None):
         """channels-last entry: input tokens [B*F*H*W, 8] -> (noise tokens [B*F*H*W, 4], ctx).  This is what
         lkgd_amd.pipeline calls between the glue kernels (no NCHW conversions inside the loop)."""
-        self.prepare()
+        with _replay.invariant():          # (a first call after invalidate() packs the weights: constants of a plan being recorded)
+            self.prepare()
         with _trace.range_("unet_forward"):
             return self._forward_tokens(tokens, B, F, H, W, timestep, encoder_hidden_states, added_time_ids,
                                         down_block_additional_residuals, mid_block_additional_residual, shard)

@@ -9,6 +9,10 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# every recorded region of the suite (and of the rank processes it spawns) runs under the replay contract check: a torch op that
+# moves device data outside a C-ABI launch / replay.step raises instead of going stale on replays (lkgd_amd/replay.py)
+os.environ.setdefault("LKGD_REPLAY_STRICT", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
