@@ -105,7 +105,10 @@ __global__ __launch_bounds__(LK_NT) void lk_fuse_kernel(const lk_params p) {
     }
     spatial[0] = acc[0] + p.b_fuse[t]; spatial[1] = acc[1] + p.b_fuse[t + LK_NT];
   }
-  // magnitudes / phases: bins 0..127 -> [4 x 128], bin 128 apart (reference :555-577)
+  // magnitudes / phases: bins 0..127 -> [4 x 128], bin 128 apart (reference :555-577).  Sign convention of the two REAL bins
+  // (DC, Nyquist): the direct DFT above accumulates sin(0) / sin(pi k) terms that are exactly +0, so im = +0 and a negative real
+  // part has phase +pi - what torch.angle(torch.fft.rfft(x)) returns on the host as well (tests/test_oracle_golden.py pins it;
+  // an FFT library that produced -0 there would give -pi, 2 pi w away through pha0 / the pha quaternion linear)
   for (int q = t; q < 4 * 129; q += LK_NT) {
     const int s = q / 129, k = q - s * 129;
     float m, ph;

@@ -145,6 +145,23 @@ def test_full_size_loop_properties(full_pipe):
     # (3) more Euler steps on the same sigma schedule family stay finite and bounded
     f = _run(pipe, lat0, img, emb, ids, 4, 1.0, 3.0)
     assert torch.isfinite(f.float()).all() and f.float().abs().max() < 1e4
+    # (4) the working set of the recorded forward (<= 20 GB, from ~55 when the plan kept every launch's
+    # output alive): the private pool the plan's scratch lives in = the eager peak of one forward (3.5 GB measured), and the
+    # replayed loop is the eager loop bit for bit
+    assert 0 < pipe.arena_reserved_bytes() <= 6e9, pipe.arena_reserved_bytes()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    resident = torch.cuda.memory_allocated()
+    g = _run(pipe, lat0, img, emb, ids, 3, 1.0, 3.0)
+    assert torch.cuda.max_memory_allocated() - resident <= 6e9
+    pipe.use_replay = False
+    try:
+        h = _run(pipe, lat0, img, emb, ids, 3, 1.0, 3.0)
+    finally:
+        pipe.use_replay = True
+    assert torch.equal(g, h)
+    pipe.release_arena()
+    assert pipe.arena_reserved_bytes() == 0
 
 
 def test_full_size_lk_joint_and_fsm_hook_properties():

@@ -237,6 +237,51 @@ def test_recorded_forward_replays_exactly(wiring):
     assert not torch.equal(again, first)
 
 
+@pytest.mark.gpu
+def test_replay_arena_cold_caches_and_contract():
+    """lkgd_amd/replay.py, round 6.  (a) The recorded forward allocates its scratch from a private pool and frees it as it goes: the
+    FIRST forward of a model - the one that also builds the lazily cached tables (frame-position embeddings, mixing factors) inside
+    the recorded region - replays bit-identically to the eager loop (the first version of the arena put a mid-region constant into
+    a block an earlier launch used as scratch; replays of that launch overwrote it).  (b) The contract check: data movement by a
+    plain torch op inside a recorded region raises; inside replay.step / replay.invariant() it is allowed."""
+    import bench
+    from lkgd_amd import ops, replay
+    from lkgd_amd.pipeline import StableVideoDiffusionPipeline
+    dev = torch.device(DEV)
+    outs = {}
+    for mode in (True, False):
+        ops._zeros.clear()                                   # process-global lazies too: cold for both runs
+        pipe = StableVideoDiffusionPipeline(unet=bench.build_unet(dev, tiny=True))
+        lat0, img, emb, ids = bench.synthetic_inputs(dev, 4, 16, 16)
+        pipe.use_replay = mode
+        pipe.scheduler.set_timesteps(3)
+        s0 = float(pipe.scheduler.init_noise_sigma)
+        outs[mode] = [pipe.denoise((lat0 * s0).half(), img, emb, ids, 3, 1.0, 3.0).clone() for _ in range(2)]
+        if mode:
+            assert 0 < pipe.arena_reserved_bytes() < 600e6
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    x = torch.ones(4, 8, device=dev, dtype=torch.float16)
+    with replay.strict(True):
+        with pytest.raises(replay.ReplayContractError):
+            with replay.record():
+                torch.cat([x, x])
+        with pytest.raises(replay.ReplayContractError):
+            with replay.record():
+                x.zero_()
+        with pytest.raises(replay.ReplayContractError):
+            with replay.record():
+                x[1:2] = 3.0
+        with replay.record() as plan:
+            y = torch.empty_like(x)                          # scratch
+            replay.step(lambda: y.copy_(x))                  # a replayed host step
+            with replay.invariant():
+                z = x * 2                                    # a declared constant
+        x.fill_(5.0)
+        plan.run()
+        assert torch.equal(y, x) and float(z[0, 0]) == 2.0
+    assert ops.PLAN is None
+
+
 def _trained_like_(model, seed):
     """Statistics a TRAINED checkpoint has and fan-in-normal weights do not (no real checkpoint can reach this box): heavy-tailed
     weights (Student-t, 3 degrees of freedom: a few entries 5-10 sigma out), attention q / k projections twice as large (scores
@@ -323,6 +368,12 @@ def test_lk_fuse_kernel_vs_oracle(B, Bd):
         for p in o.parameters():                    # the HIP model holds fp16-rounded parameters
             p.copy_(p.half().float())
         ref = o.lk_fuse(e, dd, ff)
+        # the phase of a NEGATIVE real DC / Nyquist bin is +pi with the kernel's direct DFT (imaginary part exactly +0)
+        # and with torch.fft on the host (tests/test_oracle_golden.py pins that); these inputs carry such bins, so a -pi
+        # convention anywhere would show as an O(1) error below
+        low = o.quaternion_lora_lconv(e.permute(0, 2, 1)).permute(0, 2, 1)
+        X = torch.fft.rfft(low, dim=-1)
+        assert bool((X[..., 0].real < 0).any() or (X[..., -1].real < 0).any())
     out = lk_fuse(m, e.to(DEV), d.to(DEV), f.to(DEV))
     assert out.shape == (B, 1, 1024) and out.dtype == torch.float16
     err = (out.float().cpu() - ref).abs().max().item()
