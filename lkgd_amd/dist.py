@@ -65,22 +65,27 @@ class ShardPlan:
         return [c * self.frame_shards + self.shard_index for c in range(self.cfg_groups)]
 
 
-def split_frames(num_frames: int, shards: int) -> Tuple[int, ...]:
-    """contiguous, as even as possible, larger slices first: 14 over 4 -> (4, 4, 3, 3)"""
-    if shards < 1 or shards > num_frames:
-        raise ValueError(f"cannot split {num_frames} frames over {shards} shards")
-    q, r = divmod(num_frames, shards)
-    return tuple(q + 1 if i < r else q for i in range(shards))
+def split_frames(num_frames: int, shards: int, unit: int = 1) -> Tuple[int, ...]:
+    """contiguous, as even as possible, larger slices first: 14 over 4 -> (4, 4, 3, 3).  ``unit``: slices are cut at multiples of
+    ``unit`` frames (2 with the FSM hook, which fuses frames 2k and 2k+1 - patch/patch_FSM.py:405-441: a pair must live on one
+    rank): 14 over 4 in pairs -> (4, 4, 4, 2)"""
+    if unit < 1 or num_frames % unit:
+        raise ValueError(f"{num_frames} frames are not whole groups of {unit}")
+    units = num_frames // unit
+    if shards < 1 or shards > units:
+        raise ValueError(f"cannot split {num_frames} frames over {shards} shards" + (f" in groups of {unit}" if unit > 1 else ""))
+    q, r = divmod(units, shards)
+    return tuple((q + 1 if i < r else q) * unit for i in range(shards))
 
 
-def make_plan(world: int, rank: int, num_frames: int, cfg: bool) -> ShardPlan:
+def make_plan(world: int, rank: int, num_frames: int, cfg: bool, frame_unit: int = 1) -> ShardPlan:
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad world/rank")
     cfg_groups = 2 if (cfg and world >= 2) else 1
     if world % cfg_groups:
         raise ValueError(f"world size {world} must be even when classifier-free guidance is on")
     shards = world // cfg_groups
-    splits = split_frames(num_frames, shards)
+    splits = split_frames(num_frames, shards, frame_unit)
     ci, si = divmod(rank, shards)
     return ShardPlan(world, rank, cfg_groups, shards, ci, si, splits, sum(splits[:si]), num_frames)
 

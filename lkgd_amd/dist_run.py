@@ -117,7 +117,9 @@ class DistDenoiser:
         if not dist.is_initialized():
             raise LkgdHipError("torch.distributed is not initialised")
         self.pipe = pipe
-        self.plan = make_plan(world, rank, num_frames, cfg)
+        # the FSM hook (lkgd_amd/patch_FSM.py) fuses frames 2k and 2k+1 of a clip: frame slices are then cut at even frames
+        fsm = any(getattr(m, "_lkgd_fsm", False) for m in pipe.unet.modules())
+        self.plan = make_plan(world, rank, num_frames, cfg, frame_unit=2 if (fsm and world > (2 if cfg else 1)) else 1)
         # every rank creates every group, in the same order
         self.frame_group = None
         for c in range(self.plan.cfg_groups):
@@ -143,7 +145,7 @@ class DistDenoiser:
                 controlnet_cond_scale: float = 1.0) -> torch.Tensor:
         """``pipeline.denoise`` over the ranks.  ``domain_features`` / ``flow_features`` (the LKGD UNet): the fuse is
         replicated (2 MFLOP) and every rank holds the fused embedding of BOTH CFG halves.  ``controlnet_condition``
-        [cfg, F, 3, 8h, 8w] (pipeline_stable_video_diffusion_controlnet.py:582-607): every rank embeds the condition frames of
+        [cfg * batch, F, 3, 8h, 8w] (pipeline_stable_video_diffusion_controlnet.py:582-607): every rank embeds the condition frames of
         ITS slice once per clip and runs the ControlNet-SVD encoder on its tokens before the UNet; the residuals are local
         token matrices, so nothing new crosses the links beyond the encoder's own temporal exchanges."""
         pipe, plan = self.pipe, self.plan
@@ -178,8 +180,6 @@ class DistDenoiser:
             b_local, e0 = cfg * B, 0
         ids_local = ids[e0:e0 + b_local]
         self.shard.set_entries(b_local)
-        if controlnet_condition is not None and B != 1:
-            raise LkgdHipError("the sharded ControlNet loop handles one clip per call")
         send = torch.zeros(b_local, fmax * HW, 4, dtype=torch.float16, device=dev)
         buf = torch.empty(plan.world, b_local, fmax * HW, 4, dtype=torch.float16, device=dev)
         noise_full = torch.empty(cfg * B * F * HW, 4, dtype=torch.float16, device=dev)
@@ -200,9 +200,9 @@ class DistDenoiser:
         if controlnet_condition is not None:
             if getattr(pipe, "controlnet", None) is None:
                 raise LkgdHipError("controlnet_condition given but the pipeline has no controlnet")
-            if controlnet_condition.shape[0] != cfg or controlnet_condition.shape[1] != F:
-                raise ValueError("controlnet_condition must be [cfg, frames, 3, 8h, 8w] (uncond first)")
-            cc = controlnet_condition[plan.cfg_index:plan.cfg_index + 1] if plan.cfg_groups == 2 else controlnet_condition
+            if controlnet_condition.shape[0] != cfg * B or controlnet_condition.shape[1] != F:
+                raise ValueError("controlnet_condition must be [cfg * batch, frames, 3, 8h, 8w] (uncond entries first)")
+            cc = controlnet_condition[e0:e0 + b_local]          # the rank's batch entries (its CFG half's clips)
             ctrl_local = cc[:, f0:f0 + fl].to(device=dev, dtype=torch.float16).contiguous()
             pipe.controlnet.prepare()
             pipe.controlnet._cond_tokens(ctrl_local, b_local, fl, H, W)     # once per clip, outside the recorded forward

@@ -133,7 +133,7 @@ def track_tables(block, ctx):
         raise LkgdHipError("FSM hook enabled but no tracks set: patch_FSM.update_patch(model, track=(src, dst, vis), "
                            "track_res=(H, W))")
     cache = info.setdefault("fsm_tables", {})
-    key = (ctx.H, ctx.W, ctx.N)
+    key = (ctx.H, ctx.W, ctx.N, ctx.b0, ctx.f0, ctx.B_total, ctx.F_total)
     if key in cache:
         return cache[key]
     HW, pairs = ctx.HW, ctx.N // 2
@@ -144,10 +144,16 @@ def track_tables(block, ctx):
         raise LkgdHipError(f"FSM hook: track_res {track_h}x{track_w} / {downsample} = {feat_h}x{feat_w} does not match "
                            f"the {ctx.H}x{ctx.W} feature grid")
     src_tracks, dst_tracks, vis = (torch.as_tensor(t).to(ctx.device) for t in track)
-    if src_tracks.shape != dst_tracks.shape or src_tracks.shape[0] != pairs or src_tracks.shape[-1] != 2 \
+    all_pairs = ctx.B_total * ctx.F_total // 2            # the tracks describe the WHOLE call's (batch, frame) pairs
+    if src_tracks.shape != dst_tracks.shape or src_tracks.shape[0] != all_pairs or src_tracks.shape[-1] != 2 \
             or tuple(vis.shape) != tuple(src_tracks.shape[:2]):
-        raise LkgdHipError(f"FSM hook: tracks must be [{pairs}, P, 2] (x, y) with visibility [{pairs}, P]; got "
+        raise LkgdHipError(f"FSM hook: tracks must be [{all_pairs}, P, 2] (x, y) with visibility [{all_pairs}, P]; got "
                            f"{tuple(src_tracks.shape)}, {tuple(dst_tracks.shape)}, {tuple(vis.shape)}")
+    if all_pairs != pairs:
+        # a sharded rank (lkgd_amd/dist_run.py): its local pair (entry b, q) is pair ((b0 + b) F + f0) / 2 + q of the call
+        own = [((ctx.b0 + b) * ctx.F_total + ctx.f0) // 2 + q for b in range(ctx.B) for q in range(ctx.F // 2)]
+        sel = torch.tensor(own, dtype=torch.long, device=ctx.device)
+        src_tracks, dst_tracks, vis = src_tracks[sel], dst_tracks[sel], vis[sel]
     src = (src_tracks / downsample).long()                                    # :398-399 (truncation toward zero)
     dst = (dst_tracks / downsample).long()
     dst_x = dst[..., 0].clamp(0, feat_w - 1)                                  # :400-401 (only dst is clamped)

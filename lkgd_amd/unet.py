@@ -218,11 +218,13 @@ def _eff_weight(lin, adapters=()) -> torch.Tensor:
 
 
 def _gemm_runs(ctx: "Ctx", a: torch.Tensor, out: torch.Tensor, pick, *, N: int, K: int, rowmap=None, res1=None,
-               res2=None, **kw) -> None:
+               res2=None, rows: Optional[int] = None, **kw) -> None:
     """masked-LoRA form of a projection over all T rows: one launch per run of consecutive batch entries that share a
     weight variant (lkgd_amd/lora.py).  pick(i) -> (w, bias, rowbias table or None) of run i; a row map is shifted to the
-    run's first row (idx(m) = ((m / d1) * m1 + m % d2 + c0) % md with the run start a multiple of d1 and d2)"""
-    rows = ctx.F * ctx.HW
+    run's first row (idx(m) = ((m / d1) * m1 + m % d2 + c0) % md with the run start a multiple of d1 and d2).  ``rows``: token
+    rows per batch entry in the layout of ``a`` (default: the rank's frames x pixels; the pixel-re-sharded layout of a
+    frame-sharded temporal block has all F frames of a pixel slice per entry)"""
+    rows = ctx.F * ctx.HW if rows is None else rows
     for i, (b0, b1) in enumerate(ctx.lora.runs):
         r0, r1 = b0 * rows, b1 * rows
         w, bias, rb = pick(i)
@@ -499,10 +501,15 @@ class BasicTransformerBlock(nn.Module):
         pk, T, Cc = self._pk, hA.shape[0], hA.shape[1]
         if not hasattr(pk, "wfuse"):
             raise LkgdHipError("FSM hook enabled but conv_fuse is missing (patch_FSM.initialize_joint_layers)")
-        if ctx.shard is not None:
-            raise LkgdHipError("the FSM hook pairs neighbouring batch entries and is not available under sharding")
         if ctx.N % 2:
             raise LkgdHipError("FSM hook: batch*frames must be even (hidden_states[::2] / [1::2] pairs)")
+        if ctx.shard is not None:
+            # the hook pairs rows 2k / 2k+1 of the flattened (batch, frame) axis of the WHOLE call.  A rank's local pairs are those
+            # pairs when every local entry starts on an even global row: frame slices cut at even frames (dist.make_plan(...,
+            # frame_unit=2), which DistDenoiser selects when the model carries the hook) of clips with an even frame count
+            if any(((ctx.b0 + b) * ctx.F_total + ctx.f0 - b * ctx.F) % 2 for b in range(ctx.B)):
+                raise LkgdHipError(f"FSM hook under sharding: the rank's frames [{ctx.f0}, {ctx.f0 + ctx.F}) of {ctx.F_total} split a "
+                                   "(2k, 2k+1) frame pair - build the shard plan with frame_unit=2 and an even frame count")
         from .patch_FSM import track_tables
         with _replay.invariant():            # set once per clip (update_patch): constants of the clip's plan
             fwd, bwd = track_tables(self, ctx)
@@ -570,8 +577,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         fused = base_ok and not joint
         from . import dist as _dist
         # (a level with fewer pixels than shards - the 1x1 level of the tiny test nets - keeps the gathered form)
-        resharded = (ctx.frames_sharded and ctx.lora is None and not _dist.TEMPORAL_GATHER and
-                     ctx.HW >= ctx.shard.plan.frame_shards)
+        resharded = ctx.frames_sharded and not _dist.TEMPORAL_GATHER and ctx.HW >= ctx.shard.plan.frame_shards
         # ... and the out-projection, its residual and the folded cross-attention table in the same launch (attn_tblock.hip);
         # with the joint branch on, the main branch still runs that way and only the joint branch's input is normalised apart
         one_launch = base_ok and ops.tattn_block_ok(Cc, self.attn1.heads, ctx.F, ctx.HW)
@@ -588,9 +594,7 @@ class TemporalBasicTransformerBlock(nn.Module):
                 with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
                     pk.a1.wfront = pack_tfront(pk.a1.wqkv, self.attn1.heads)
             ops.tattn_front(m1, pk.a1.wfront, pk.a1.bqkv, att, ctx.B, ctx.F, ctx.HW, self.attn1.heads)
-        elif ctx.lora is not None:
-            if ctx.frames_sharded:
-                raise LkgdHipError("masked LoRA is not available under frame sharding")
+        elif ctx.lora is not None and not ctx.frames_sharded:
             va = [_attn_variant(self, "a1", ctx, i, False) for i in range(len(ctx.lora.runs))]
             qkv = ctx.new(T, 3 * Cc)
             _gemm_runs(ctx, ln1, qkv, lambda i: (va[i].wqkv, va[i].bqkv, None), N=3 * Cc, K=Cc)
@@ -617,7 +621,15 @@ class TemporalBasicTransformerBlock(nn.Module):
             pxl = Tp // (Ft * ctx.B)
             attp = ctx.new(Tp, Cc)
             ln1p = None
-            if ops.tattn_front_ok(Cc, self.attn1.heads, Ft, pxl):
+            if ctx.lora is not None:
+                # masked LoRA (round 6): a rank holds its slice of every clip of its CFG half, so the per-entry weight variants
+                # apply to its entries unchanged - one launch per entry run, rows per entry = all F frames of the pixel slice
+                va = [_attn_variant(self, "a1", ctx, i, False) for i in range(len(ctx.lora.runs))]
+                ln1p = ops.layernorm(m1p, None, None, 1e-5)
+                qkv = ctx.new(Tp, 3 * Cc)
+                _gemm_runs(ctx, ln1p, qkv, lambda i: (va[i].wqkv, va[i].bqkv, None), N=3 * Cc, K=Cc, rows=Ft * pxl)
+                ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], attp, ctx.B, Ft, pxl, self.attn1.heads)
+            elif ops.tattn_front_ok(Cc, self.attn1.heads, Ft, pxl):
                 if getattr(pk.a1, "wfront", None) is None:
                     from .packing import pack_tfront
                     with _replay.invariant():      # built once from the weights: a constant of any plan being recorded
@@ -637,7 +649,11 @@ class TemporalBasicTransformerBlock(nn.Module):
                 if ln1p is None:
                     ln1p = ops.layernorm(m1p, None, None, 1e-5)
                 qkvj, attjp = ctx.new(Tp, 3 * Cc), ctx.new(Tp, Cc)
-                ops.gemm(ln1p, pk.a1n.wqkv, qkvj, M=Tp, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
+                if ctx.lora is None:
+                    ops.gemm(ln1p, pk.a1n.wqkv, qkvj, M=Tp, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
+                else:
+                    vjp = [_attn_variant(self, "a1n", ctx, i, False) for i in range(len(ctx.lora.runs))]
+                    _gemm_runs(ctx, ln1p, qkvj, lambda i: (vjp[i].wqkv, vjp[i].bqkv, None), N=3 * Cc, K=Cc, rows=Ft * pxl)
                 ops.attn_temporal(qkvj[:, :Cc], qkvj[:, Cc:2 * Cc], qkvj[:, 2 * Cc:], attjp, ctx.B, Ft, pxl, self.attn1n.heads,
                                   kv_b_map=ctx.temporal_partner)
                 att_joint = ctx.shard.to_frames(attjp, ctx.HW)
@@ -648,16 +664,28 @@ class TemporalBasicTransformerBlock(nn.Module):
             ln1f = ctx.shard.gather(ln1)
             Tf = ln1f.shape[0]
             q, kvf = ctx.new(T, Cc), ctx.new(Tf, 2 * Cc)
-            ops.gemm(ln1, pk.a1.wqkv[:Cc], q, M=T, N=Cc, K=Cc, bias=pk.a1.bqkv[:Cc])
-            ops.gemm(ln1f, pk.a1.wqkv[Cc:], kvf, M=Tf, N=2 * Cc, K=Cc, bias=pk.a1.bqkv[Cc:])
+            if ctx.lora is None:
+                ops.gemm(ln1, pk.a1.wqkv[:Cc], q, M=T, N=Cc, K=Cc, bias=pk.a1.bqkv[:Cc])
+                ops.gemm(ln1f, pk.a1.wqkv[Cc:], kvf, M=Tf, N=2 * Cc, K=Cc, bias=pk.a1.bqkv[Cc:])
+            else:
+                va = [_attn_variant(self, "a1", ctx, i, False) for i in range(len(ctx.lora.runs))]
+                _gemm_runs(ctx, ln1, q, lambda i: (va[i].wqkv[:Cc], va[i].bqkv[:Cc], None), N=Cc, K=Cc)
+                _gemm_runs(ctx, ln1f, kvf, lambda i: (va[i].wqkv[Cc:], va[i].bqkv[Cc:], None), N=2 * Cc, K=Cc,
+                           rows=ctx.F_total * ctx.HW)
             ops.attn_temporal(q, kvf[:, :Cc], kvf[:, Cc:], att, ctx.B, ctx.F_total, ctx.HW, self.attn1.heads,
                               Fq=ctx.F)
             if joint:         # attn1n: local query frames against the partner entry's keys / values of ALL frames
                 if ctx.temporal_partner is None:
                     raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
                 qj, kvj, att_joint = ctx.new(T, Cc), ctx.new(Tf, 2 * Cc), ctx.new(T, Cc)
-                ops.gemm(ln1, pk.a1n.wqkv[:Cc], qj, M=T, N=Cc, K=Cc, bias=pk.a1n.bqkv[:Cc])
-                ops.gemm(ln1f, pk.a1n.wqkv[Cc:], kvj, M=Tf, N=2 * Cc, K=Cc, bias=pk.a1n.bqkv[Cc:])
+                if ctx.lora is None:
+                    ops.gemm(ln1, pk.a1n.wqkv[:Cc], qj, M=T, N=Cc, K=Cc, bias=pk.a1n.bqkv[:Cc])
+                    ops.gemm(ln1f, pk.a1n.wqkv[Cc:], kvj, M=Tf, N=2 * Cc, K=Cc, bias=pk.a1n.bqkv[Cc:])
+                else:
+                    vjg = [_attn_variant(self, "a1n", ctx, i, False) for i in range(len(ctx.lora.runs))]
+                    _gemm_runs(ctx, ln1, qj, lambda i: (vjg[i].wqkv[:Cc], vjg[i].bqkv[:Cc], None), N=Cc, K=Cc)
+                    _gemm_runs(ctx, ln1f, kvj, lambda i: (vjg[i].wqkv[Cc:], vjg[i].bqkv[Cc:], None), N=2 * Cc, K=Cc,
+                               rows=ctx.F_total * ctx.HW)
                 ops.attn_temporal(qj, kvj[:, :Cc], kvj[:, Cc:], att_joint, ctx.B, ctx.F_total, ctx.HW, self.attn1n.heads,
                                   kv_b_map=ctx.temporal_partner, Fq=ctx.F)
         xtab = ctx.xb_all[:, pk.xoff:pk.xoff + Cc]
@@ -697,12 +725,13 @@ class TemporalBasicTransformerBlock(nn.Module):
         if ctx.temporal_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set")
         vj = None
+        if ctx.lora is not None:
+            vj = [_attn_variant(self, "a1n", ctx, i, False) for i in range(len(ctx.lora.runs))]
         if att is None:
             qkv = ctx.new(T, 3 * Cc)
-            if ctx.lora is None:
+            if vj is None:
                 ops.gemm(ln1, pk.a1n.wqkv, qkv, M=T, N=3 * Cc, K=Cc, bias=pk.a1n.bqkv)
             else:
-                vj = [_attn_variant(self, "a1n", ctx, i, False) for i in range(len(ctx.lora.runs))]
                 _gemm_runs(ctx, ln1, qkv, lambda i: (vj[i].wqkv, vj[i].bqkv, None), N=3 * Cc, K=Cc)
             att = ctx.new(T, Cc)
             ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.B, ctx.F, ctx.HW,
@@ -1373,7 +1402,8 @@ class _UNetBase(nn.Module):
                                    f"pairs; mask {full}, entries {ctx.b0}..{ctx.b0 + ctx.B - 1}")
             if flip and ctx.frames_sharded:
                 raise LkgdHipError("joint attention with flip=True pairs frame f with frame F-1-f of the partner clip, which "
-                                   "lives on another rank under frame sharding")
+                                   "lives on another rank under frame sharding: run flip=True on one GPU or on the CFG-parallel "
+                                   "layout (2 GPUs), where a rank holds all frames of both clips")
             mask = own
 
         def partner(n_rows, group):
@@ -1442,8 +1472,6 @@ class _UNetBase(nn.Module):
         self._time_embed(ctx, timestep, added_time_ids)
         self._joint_maps(ctx)
         if pk.has_lora:
-            if ctx.frames_sharded:
-                raise LkgdHipError("LoRA wrappers under frame sharding: merge them first (lkgd_amd.lora.merge_lora)")
             from . import lora as _lora
             ctx.lora = _lora.entry_plan(self, ctx.B, ctx.entry_partner, ctx.B_total, ctx.b0)
         self._cross_tables(ctx, encoder_hidden_states)
