@@ -208,6 +208,15 @@ class _Region(TorchFunctionMode):
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        name = getattr(func, "__name__", str(func))
+        allowed = getattr(_tls, "allow", 0) > 0
+        inplace = name in _INPLACE_DUNDER or (name.endswith("_") and not name.startswith("__")) or kwargs.get("out") is not None
+        if inplace and STRICT and not allowed:
+            # an in-place write (the target is the first argument or out=): checked BEFORE it runs, so a refused op has no effect
+            tgt = kwargs.get("out") if kwargs.get("out") is not None else (args[0] if args else None)
+            if isinstance(tgt, torch.Tensor) and tgt.is_cuda:
+                _violation(f"in-place torch op '{name}' writes a device tensor inside a recorded region outside replay.step: a "
+                           "replay would not redo it", name)
         if self.arena is not None and func in _SCRATCH:
             with self.arena.allocating():
                 out = func(*args, **kwargs)
@@ -217,16 +226,7 @@ class _Region(TorchFunctionMode):
             self.keep.append(out)
             if not STRICT:
                 return out
-        if func in _SCRATCH:
-            return out
-        name = getattr(func, "__name__", str(func))
-        allowed = getattr(_tls, "allow", 0) > 0
-        if name in _INPLACE_DUNDER or (name.endswith("_") and not name.startswith("__")) or kwargs.get("out") is not None:
-            # an in-place write (the target is the first argument or out=): never a new tensor
-            tgt = kwargs.get("out") if kwargs.get("out") is not None else (args[0] if args else None)
-            if STRICT and not allowed and isinstance(tgt, torch.Tensor) and tgt.is_cuda:
-                _violation(f"in-place torch op '{name}' writes a device tensor inside a recorded region outside replay.step: a "
-                           "replay would not redo it", name)
+        if func in _SCRATCH or inplace:
             return out
         outs = _tensors(out, [])
         if not outs:

@@ -173,8 +173,16 @@ def test_fsm_track_tables_match_reference_indexing():
                        torch.randint(-4, 2 * fh + 4, (pairs, P), generator=g)], -1).float()
     vis = (torch.rand(pairs, P, generator=g) > 0.3).float()
     blk = SimpleNamespace(_tome_info={"fsm_tables": {}}, track=(src, dst, vis), track_res=(2 * fh, 2 * fw))
-    ctx = SimpleNamespace(H=fh, W=fw, HW=fh * fw, N=2 * pairs, device=torch.device("cpu"))
+    ctx = SimpleNamespace(H=fh, W=fw, HW=fh * fw, N=2 * pairs, B=1, F=2 * pairs, b0=0, f0=0, B_total=1, F_total=2 * pairs,
+                          device=torch.device("cpu"))
     (off, pt, gi, v), (boff, bpt, bgi, _) = patch_FSM.track_tables(blk, ctx)
+    # a sharded rank (round 6): entries [b0, b0 + B) x frames [f0, f0 + F) of a 2-entry x 6-frame call take their pairs' rows
+    if pairs == 3:
+        blk6 = SimpleNamespace(_tome_info={"fsm_tables": {}}, track=(torch.cat([src, src]), torch.cat([dst, dst]),
+                                                                     torch.cat([vis, 1.0 - vis])), track_res=(2 * fh, 2 * fw))
+        c2 = SimpleNamespace(H=fh, W=fw, HW=fh * fw, N=2, B=1, F=2, b0=1, f0=4, B_total=2, F_total=6, device=torch.device("cpu"))
+        (_, _, gi2, v2), _ = patch_FSM.track_tables(blk6, c2)          # global pair (1 * 6 + 4) / 2 = 5 = the second copy's pair 2
+        assert torch.equal(gi2, gi.reshape(pairs, -1)[2].reshape(-1)) and torch.equal(v2, 1.0 - v.reshape(pairs, -1)[2].reshape(-1))
     assert off.dtype == torch.int32 and off.numel() == pairs * fh * fw + 1 and int(off[-1]) == pairs * P
     sidx = (src / 2).long()
     sidx = sidx[..., 0] + sidx[..., 1] * fw

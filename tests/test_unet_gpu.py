@@ -271,6 +271,7 @@ def test_replay_arena_cold_caches_and_contract():
         with pytest.raises(replay.ReplayContractError):
             with replay.record():
                 x[1:2] = 3.0
+        assert float(x.float().sum()) == 32.0                # refused before they ran
         with replay.record() as plan:
             y = torch.empty_like(x)                          # scratch
             replay.step(lambda: y.copy_(x))                  # a replayed host step
