@@ -197,7 +197,7 @@ def test_fsm_track_tables_match_reference_indexing():
                 assert p_[int(o_[r]):int(o_[r + 1])].tolist() == want
         assert g_.tolist() == gat.reshape(-1).tolist()
     assert torch.equal(v, vis.reshape(-1))
-    assert patch_FSM.track_tables(blk, ctx) is blk._tome_info["fsm_tables"][(fh, fw, 2 * pairs)]   # cached
+    assert patch_FSM.track_tables(blk, ctx) is blk._tome_info["fsm_tables"][(fh, fw, 2 * pairs, 0, 0, 1, 2 * pairs)]   # cached
     bad = SimpleNamespace(_tome_info={"fsm_tables": {}}, track=(src - 100.0, dst, vis), track_res=(2 * fh, 2 * fw))
     with pytest.raises(LkgdHipError):
         patch_FSM.track_tables(bad, ctx)
