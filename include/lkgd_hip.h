@@ -124,8 +124,6 @@ int lkgd_gemm_colstats_block(const lkgd_gemm_desc* d);
  * idle more than a tenth of their columns (N = 256, 512, 768: the temporal VAE decoder's widths, diffusers
  * AutoencoderKLTemporalDecoder block_out_channels (128, 256, 512, 512)) - introspection for tests and tools */
 int lkgd_gemm_wide_tile_n(int N);
-void lkgd_debug_set_wide_tile_n(int wn);   /* A/B knob: force 256 / 320 where that width divides N; 0 = the rule */
-void lkgd_debug_set_wide_tile_m(int wm);   /* A/B knob: force 192 / 256 tile rows on unsliced launches of that program; 0 = the rule */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 2. GroupNorm (32 groups) statistics + apply + SiLU on channels-last tokens.
@@ -461,40 +459,10 @@ int lkgd_lk_fuse(const float* e, const float* d, const float* f, int32_t B, int3
 /* version / build info: "lkgd_hip <n> gfx950" */
 const char* lkgd_version(void);
 
-/* ---------------------------------------------------------------------------------------------------------------
- * DEBUG / MEASUREMENT KNOBS - not part of the reference-facing interface, NOT thread-safe.
- *    Everything above keeps its promise of "no global state" only while none of these is called: each one writes a
- *    process-global variable that every later launch of the op, on any thread and stream, reads.  They exist for the
- *    A/B tools under tools/ and for the per-variant parity tests (tests/test_kernels_gpu.py); a product caller never
- *    needs them.  Value 0 (or -1 where noted) restores the automatic behaviour.
- *      lkgd_debug_set_gemm_variant(v)   force a tile program of lkgd_gemm_f16 where it applies: 1 = 128x128, 2 = 256x128 ring, 7 = 128x128 on a four-stage ring (few-row problems),
- *                                       3 = persistent 256x128, 4 = 256x320, 5 = row-panel, 6 = resident-weight; 0 = auto
- *      lkgd_debug_set_gemm_splitk(on)   0 = never cut K into slices
- *      lkgd_debug_set_mid_model(tk, fix, red, tbs, forced)   cost model of the four-stage 128x128 program's K slicing (us per
- *                                       K-tile, us per workgroup, us per reduce pass, TB/s of the reduce pass; <= 0 keeps a value);
- *                                       forced > 0 = that many slices where legal
- *      lkgd_debug_set_wide_ksplit(k)    force k K-slices on the 256x320 program where legal; 0 = rule
- *      lkgd_debug_set_wide_lds_out(on)  256x320 program: 0 = direct 8-byte stores everywhere, 1 / -1 = rows through LDS where used
- *      lkgd_debug_set_attn_waves(nw)    spatial attention: waves per workgroup (4 / 8 / 16); 0 = by sequence length
- *      lkgd_debug_set_attn_kvb(kvb)     spatial attention: keys per barrier (64 / 128); 0 = default
- *      lkgd_debug_set_attn_pipe(mode)   spatial attention: 1 = never the software-pipelined program (attn_spatial_pipe.hip),
- *                                       2 = wherever it is legal (S >= 128; S % 128 != 0 runs its masked form); 0 = by sequence length
- *      lkgd_debug_set_gn_apply_kb(kb) / lkgd_debug_set_gn_stats_kb(kb)   GroupNorm chunk sizes in KiB (>= 32)
- *      lkgd_debug_set_gn_target_wgs(n)  workgroups a GroupNorm pass aims at on small maps (chunks shrink to 8 KiB); 1 = fixed sizes
- * ------------------------------------------------------------------------------------------------------------- */
-void lkgd_debug_set_gemm_variant(int32_t v);
-void lkgd_debug_set_gemm_splitk(int32_t on);
-void lkgd_debug_set_mid_model(float tk_us, float fix_us, float red_us, float red_tbs, int32_t forced);
-void lkgd_debug_set_wide_ksplit(int32_t k);
-void lkgd_debug_set_wide_lds_out(int32_t on);
-void lkgd_debug_set_attn_waves(int32_t nw);
-void lkgd_debug_set_attn_kvb(int32_t kvb);
-void lkgd_debug_set_attn_pipe(int32_t mode);
-void lkgd_debug_set_gn_apply_kb(int32_t kb);
-void lkgd_debug_set_gn_stats_kb(int32_t kb);
-void lkgd_debug_set_gn_target_wgs(int32_t n);
-void lkgd_debug_set_gn_small(int32_t on);      /* 0 = lkgd_groupnorm_silu always takes the three launches */
-void lkgd_debug_set_gn_small_limits(int64_t total_bytes);   /* tensor size up to which the one-launch form is taken */
+/* The debug / measurement knobs (lkgd_debug_set_*: forced tile programs, chunk sizes - the A/B tools under tools/ and the
+ * per-variant parity tests use them) are NOT part of this interface: they are declared in include/lkgd_hip_debug.h, which no
+ * product caller includes, and their state is per host thread (round 6), so the promise above - no process-global state, safe
+ * to call from several host threads - holds whether or not somebody turns a knob. */
 
 #ifdef __cplusplus
 }

@@ -60,8 +60,6 @@ SYMBOLS = {
     "lkgd_gemm_f16": (_i32, [C.POINTER(GemmDesc), _vp]),
     "lkgd_gemm_colstats_block": (_i32, [C.POINTER(GemmDesc)]),
     "lkgd_gemm_wide_tile_n": (_i32, [_i32]),
-    "lkgd_debug_set_wide_tile_n": (None, [_i32]),
-    "lkgd_debug_set_wide_tile_m": (None, [_i32]),
     "lkgd_groupnorm_stats_cols": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _vp, _vp]),
     "lkgd_groupnorm_chunks": (_i32, [_i64, _i32]),
     "lkgd_groupnorm_stats": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _vp]),
@@ -109,6 +107,12 @@ SYMBOLS = {
     "lkgd_lk_fuse": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "lkgd_version": (C.c_char_p, []),
     # debug / measurement knobs (process-global, not thread-safe: include/lkgd_hip.h, last section)
+}
+
+#: include/lkgd_hip_debug.h: A/B and test knobs, per host thread; bound on the same library object, not part of the product interface
+DEBUG_SYMBOLS = {
+    "lkgd_debug_set_wide_tile_n": (None, [_i32]),
+    "lkgd_debug_set_wide_tile_m": (None, [_i32]),
     "lkgd_debug_set_gemm_variant": (None, [_i32]),
     "lkgd_debug_set_gemm_splitk": (None, [_i32]),
     "lkgd_debug_set_mid_model": (None, [C.c_float, C.c_float, C.c_float, C.c_float, _i32]),
@@ -139,17 +143,26 @@ def lib() -> C.CDLL:
             l = C.CDLL(LIB_PATH)
         except OSError as e:
             raise LkgdHipError(f"cannot load {LIB_PATH}: {e}") from e
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(l, name)       # AttributeError here = header / library mismatch
-            fn.restype, fn.argtypes = res, args
-        if os.environ.get("LKGD_ATTN_PIPE"):     # A/B measurements only (same-box bench pairs): 1 = never the software-pipelined
-            l.lkgd_debug_set_attn_pipe(int(os.environ["LKGD_ATTN_PIPE"]))   # attention program, 2 = wherever legal
-        for env, fn in (("LKGD_GN_TARGET_WGS", "lkgd_debug_set_gn_target_wgs"), ("LKGD_GEMM_VARIANT", "lkgd_debug_set_gemm_variant"),
-                        ("LKGD_GN_SMALL", "lkgd_debug_set_gn_small")):
-            if os.environ.get(env):              # A/B measurements only
-                getattr(l, fn)(int(os.environ[env]))
+        for table in (SYMBOLS, DEBUG_SYMBOLS):
+            for name, (res, args) in table.items():
+                fn = getattr(l, name)       # AttributeError here = header / library mismatch
+                fn.restype, fn.argtypes = res, args
         _lib = l
+    if _ENV_KNOBS and not getattr(_knob_tls, "done", False):
+        # A/B measurements only (same-box bench pairs).  The knobs are per host thread in the library, so an environment knob is
+        # applied once on every thread that reaches the library
+        _knob_tls.done = True
+        for fn, v in _ENV_KNOBS:
+            getattr(_lib, fn)(v)
     return _lib
+
+
+#: LKGD_ATTN_PIPE: 1 = never the software-pipelined attention program, 2 = wherever legal; LKGD_GN_TARGET_WGS, LKGD_GEMM_VARIANT,
+#: LKGD_GN_SMALL: see include/lkgd_hip_debug.h
+_ENV_KNOBS = [(fn, int(os.environ[env])) for env, fn in (
+    ("LKGD_ATTN_PIPE", "lkgd_debug_set_attn_pipe"), ("LKGD_GN_TARGET_WGS", "lkgd_debug_set_gn_target_wgs"),
+    ("LKGD_GEMM_VARIANT", "lkgd_debug_set_gemm_variant"), ("LKGD_GN_SMALL", "lkgd_debug_set_gn_small")) if os.environ.get(env)]
+_knob_tls = __import__("threading").local()
 
 
 def check(rc: int, what: str) -> None:

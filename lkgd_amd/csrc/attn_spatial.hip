@@ -309,9 +309,9 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : 2) void attn_spatial_kernel
   }
 }
 
-static int attn_nw_override = 0;     // A/B knobs: waves per workgroup / keys per stage regardless of S
-static int attn_kvb_override = 0;
-static int attn_pipe_mode = 0;       // 0 = by rule, 1 = never the software-pipelined program, 2 = wherever it is legal
+static thread_local int attn_nw_override = 0;     // A/B knobs: waves per workgroup / keys per stage regardless of S
+static thread_local int attn_kvb_override = 0;
+static thread_local int attn_pipe_mode = 0;       // 0 = by rule, 1 = never the software-pipelined program, 2 = wherever it is legal
 extern "C" void lkgd_debug_set_attn_waves(int nw) { attn_nw_override = nw; }
 extern "C" void lkgd_debug_set_attn_kvb(int kvb) { attn_kvb_override = kvb; }
 extern "C" void lkgd_debug_set_attn_pipe(int mode) { attn_pipe_mode = mode; }

@@ -472,7 +472,7 @@ extern "C" int lkgd_gemm_resw_colstats_ok(const lkgd_gemm_desc* d);
 // 3 = force the persistent streaming kernel (256x128), 4 = force the wide persistent kernel (256x320),
 // 5 = force the register-resident row-panel kernel where it applies (plain A, K <= 320),
 // 6 = force the resident-weight kernel where it applies (plain A, K <= 320, N % 160 == 0)
-static int gemm_variant_override = 0;
+static thread_local int gemm_variant_override = 0;
 extern "C" void lkgd_debug_set_gemm_variant(int v) { gemm_variant_override = (v >= 1 && v <= 7) ? v : 0; }   // 7 = 128x128 on the four-stage ring
 extern "C" void lkgd_debug_set_gemm_splitk(int on);
 
@@ -485,8 +485,8 @@ extern "C" void lkgd_debug_set_gemm_splitk(int on);
 // CFG-parallel rank) want 2 - 3x3 conv 0.274 -> 0.200, FF-out 0.135 -> 0.108; 36 tiles (a rank of 8) want 5-6 even at
 // 10-K-tile slices (temporal conv 0.046 vs 0.050 on 128x128 tiles); below 48 K-tiles the fp32 partials cost more than the idle
 // CUs (9216 x 640 x 1920: 0.046 split vs 0.039 on 128x128 tiles).
-static bool gemm_splitk_enabled = true;
-static int wide_ksplit_forced = 0;      // tools/micro/ksplit_sweep.py: force this slice count where it is legal
+static thread_local bool gemm_splitk_enabled = true;
+static thread_local int wide_ksplit_forced = 0;      // tools/micro/ksplit_sweep.py: force this slice count where it is legal
 extern "C" void lkgd_debug_set_wide_ksplit(int k) { wide_ksplit_forced = k < 0 ? 0 : k; }
 static int wide_split(const lkgd_gemm_desc* d, long long tiles_wide, int cus) {
   if (d->geglu || !d->workspace || !aligned16(d->workspace)) return 0;
@@ -517,8 +517,8 @@ extern "C" void lkgd_debug_set_gemm_splitk(int on) { gemm_splitk_enabled = on !=
 // workgroup costs a fixed part (prologue, pipeline fill, epilogue or partial-tile store) plus its K-tiles; slicing adds the
 // reduce pass, which reads ks fp32 copies of the output.  Constants from tools/micro/mid_knobs.py (time over K at 2304 x 1280:
 // 0.75 us per K-tile, 5-6 us fixed; profiles/r05_gemm_mid_knobs.txt); 1 = unsplit.
-static float mid_tk_us = 0.75f, mid_fix_us = 6.0f, mid_red_us = 5.0f, mid_red_tbs = 3.5f;
-static int mid_ksplit_forced = 0;
+static thread_local float mid_tk_us = 0.75f, mid_fix_us = 6.0f, mid_red_us = 5.0f, mid_red_tbs = 3.5f;
+static thread_local int mid_ksplit_forced = 0;
 extern "C" void lkgd_debug_set_mid_model(float tk, float fix, float red, float tbs, int forced) {
   if (tk > 0) mid_tk_us = tk;
   if (fix > 0) mid_fix_us = fix;

@@ -567,15 +567,15 @@ __global__ __launch_bounds__(WNT, 2) __attribute__((amdgpu_num_vgpr(96))) void l
 }
 
 // ksplit > 1: K is cut into ksplit equal slices (ksplit divides K / 64); the caller runs lkgd_gemm_splitk_reduce afterwards
-static int wide_lds_out_override = -1;     // A/B knob: 0 = direct 8-byte stores everywhere, 1 / -1 = rows through LDS where used
+static thread_local int wide_lds_out_override = -1;     // A/B knob: 0 = direct 8-byte stores everywhere, 1 / -1 = rows through LDS where used
 extern "C" void lkgd_debug_set_wide_lds_out(int on) { wide_lds_out_override = on; }
 
 // the 256x256 form serves channel counts that are whole 256-column tiles and not whole 320-column ones (256, 512, 768 ...)
 // and would leave more than a tenth of the 320-wide tile columns idle (3072 = 9.6 x 320 stays on 320)
-static int wide_tile_n_forced = 0;      // A/B knob (tools/micro/wide_tile_n.py): 256 / 320 where that width divides N, 0 = the rule
+static thread_local int wide_tile_n_forced = 0;      // A/B knob (tools/micro/wide_tile_n.py): 256 / 320 where that width divides N, 0 = the rule
 extern "C" void lkgd_debug_set_wide_tile_n(int wn) { wide_tile_n_forced = (wn == 256 || wn == 320) ? wn : 0; }
 extern "C" int lkgd_debug_wide_tile_n_forced() { return wide_tile_n_forced; }
-static int wide_tile_m_forced = 0;      // A/B knob: 192 / 256 tile rows (0 = the rule of gemm.hip::gemm_wide_form)
+static thread_local int wide_tile_m_forced = 0;      // A/B knob: 192 / 256 tile rows (0 = the rule of gemm.hip::gemm_wide_form)
 extern "C" void lkgd_debug_set_wide_tile_m(int wm) { wide_tile_m_forced = (wm == 192 || wm == 256) ? wm : 0; }
 extern "C" int lkgd_debug_wide_tile_m_forced() { return wide_tile_m_forced; }
 extern "C" int lkgd_gemm_wide_tile_n(int N) {

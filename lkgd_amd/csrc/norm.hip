@@ -7,11 +7,11 @@
 // levels, every level of a frame-sharded rank - are cut finer, down to 8 KiB, so that a launch still has about GN_TARGET_WGS
 // workgroups: with 128-KiB chunks the 18x32 map of a rank of 8 (5.9 MB) was 48 workgroups walking 512 bytes per thread one
 // 8-load batch after the other (8-10 us per launch, profiles/r05_plan_profile_base.txt).
-static int gn_apply_kb = 32;
+static thread_local int gn_apply_kb = 32;
 extern "C" void lkgd_debug_set_gn_apply_kb(int kb) { gn_apply_kb = kb < 32 ? 32 : kb; }
-static int gn_stats_kb = 128;
+static thread_local int gn_stats_kb = 128;
 extern "C" void lkgd_debug_set_gn_stats_kb(int kb) { gn_stats_kb = kb < 32 ? 32 : kb; }
-static int gn_target_wgs = 1024;
+static thread_local int gn_target_wgs = 1024;
 extern "C" void lkgd_debug_set_gn_target_wgs(int n) { gn_target_wgs = n < 1 ? 1 : n; }   // 1 = the fixed chunk sizes only
 static inline int gn_rows_kb(int C, int kb, long long rows_per_sample, long long nsamples) {
   int rmax = kb * 1024 / (C * 2);
@@ -527,10 +527,10 @@ __global__ __launch_bounds__(GN_SMALL_NT) void gn_small_kernel(const half_t* x0,
   }
 }
 
-static int gn_small_on = 1;                 // A/B knob: 0 = always the three launches
+static thread_local int gn_small_on = 1;                 // A/B knob: 0 = always the three launches
 extern "C" void lkgd_debug_set_gn_small(int on) { gn_small_on = on != 0; }
 #define GN_SMALL_LDS (48 * 1024)
-static long long gn_small_max_bytes = 10LL * 1024 * 1024 + 512 * 1024;
+static thread_local long long gn_small_max_bytes = 10LL * 1024 * 1024 + 512 * 1024;
 extern "C" void lkgd_debug_set_gn_small_limits(int64_t total_bytes) { gn_small_max_bytes = total_bytes; }
 // does the one-launch form apply?  A workgroup reads its group as C/32-channel pieces of every row (20-160 bytes of each
 // 128-byte line: ~1.3 TB/s chip-wide against the chunked passes' whole rows), so it pays only while the launch overheads of

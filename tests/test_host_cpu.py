@@ -19,12 +19,49 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(lkgd_[a-z0-9_]+)\s*\(", hdr))
     declared.discard("lkgd_gemm_desc")
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert not any(s.startswith("lkgd_debug") for s in declared)          # the product header carries no knob
+    dbg = open(os.path.join(REPO, "include", "lkgd_hip_debug.h")).read()
+    dbg_declared = set(re.findall(r"^void (lkgd_debug_[a-z0-9_]+)\s*\(", dbg, re.M))
+    assert dbg_declared == set(_lib.DEBUG_SYMBOLS), dbg_declared ^ set(_lib.DEBUG_SYMBOLS)
     lib = _lib.lib()                       # loads liblkgd_hip.so (links libamdhip64; no GPU needed to load)
-    for s in declared:
+    for s in declared | dbg_declared:
         assert hasattr(lib, s), s
     assert lib.lkgd_version().decode().startswith("lkgd_hip")
     # 31 int32/float fields, padded to 8; workspace + size; colstats; ln_colsum + ln_eps + pad
     assert ctypes.sizeof(_lib.GemmDesc) == 9 * 8 + 31 * 4 + 4 + 16 + 8 + 16
+
+
+def test_debug_knobs_are_per_thread():
+    """include/lkgd_hip_debug.h: a knob set by one host thread does not reach another thread's launches ("no global
+    state; safe to call from multiple host threads").  lkgd_gemm_wide_tile_n is a host-side introspection of the tile rule that
+    honours the forced width, and lkgd_groupnorm_chunks honours the chunk-size knobs: both are read from two threads at once."""
+    import threading
+    from lkgd_amd import _lib
+    lib = _lib.lib()
+    assert lib.lkgd_gemm_wide_tile_n(1280) == 320
+    base_chunks = lib.lkgd_groupnorm_chunks(14 * 9216, 320)
+    seen, gate_a, gate_b = {}, threading.Event(), threading.Event()
+
+    def thread_a():
+        lib.lkgd_debug_set_wide_tile_n(256)
+        lib.lkgd_debug_set_gn_apply_kb(64)
+        seen["a"] = (lib.lkgd_gemm_wide_tile_n(1280), lib.lkgd_groupnorm_chunks(14 * 9216, 320))
+        gate_a.set()
+        gate_b.wait(10)                                   # stay alive, knob set, while thread b looks
+        seen["a2"] = lib.lkgd_gemm_wide_tile_n(1280)
+        lib.lkgd_debug_set_wide_tile_n(0)
+
+    def thread_b():
+        gate_a.wait(10)
+        seen["b"] = (lib.lkgd_gemm_wide_tile_n(1280), lib.lkgd_groupnorm_chunks(14 * 9216, 320))
+        lib.lkgd_debug_set_wide_tile_n(320)
+        gate_b.set()
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert seen["a"][0] == 256 and seen["a2"] == 256 and seen["a"][1] != base_chunks
+    assert seen["b"] == (320, base_chunks)
+    assert lib.lkgd_gemm_wide_tile_n(1280) == 320 and lib.lkgd_groupnorm_chunks(14 * 9216, 320) == base_chunks   # this thread: untouched
 
 
 def test_gemm_desc_validation_without_gpu():
