@@ -449,7 +449,14 @@ class Gen:
                 continue
             if "nobar" in knob and i.kind in ("barrier", "waitvm", "vmem"):
                 continue
+            if "dmapad" in knob and i.kind == "waitvm":          # (twice the operations in flight: the counted waits double)
+                n = int(i.text.split("(")[1].rstrip(")"))
+                i = Ins("s_waitcnt vmcnt(%d)" % (2 * n), "waitvm")
             keep.append(i)
+            # "dmapad" (round 6): every LDS-DMA issued twice (same bytes to the same place) - the L2 -> LDS fill, its issue slots and
+            # the LDS write traffic of a form whose chunks serve two waves instead of four (the C = 640 wave-pair form)
+            if "dmapad" in knob and i.kind == "vmem":
+                keep.append(i)
             # sensitivity knobs that leave the RESULT (and so the data the MFMAs see, and the clock) unchanged: every GEGLU
             # instruction followed by a dead move / every fragment read issued twice
             if "valupad" in knob and i.kind in ("valu", "trans") and "cost" in i.meta:
