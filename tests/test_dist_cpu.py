@@ -33,6 +33,20 @@ def test_split_and_plans():
                                (1, 11, 14)]
     with pytest.raises(ValueError):
         make_plan(3, 0, 14, cfg=True)
+    # round 6: frame slices cut at multiples of `frame_unit` (the FSM hook fuses frames 2k / 2k+1: a pair lives on one rank)
+    assert split_frames(14, 4, 2) == (4, 4, 4, 2) and split_frames(14, 2, 2) == (8, 6) and split_frames(8, 4, 2) == (2, 2, 2, 2)
+    assert split_frames(14, 7, 2) == (2,) * 7
+    with pytest.raises(ValueError):
+        split_frames(14, 8, 2)                 # more shards than pairs
+    with pytest.raises(ValueError):
+        split_frames(13, 2, 2)                 # an odd clip has no whole pairs
+    p = make_plan(8, 7, 14, cfg=True, frame_unit=2)
+    assert p.splits == (4, 4, 4, 2) and p.f0 == 12 and p.f_local == 2 and all(s % 2 == 0 for s in p.splits)
+    # one frame slice (pure CFG-parallel) with several entries per rank: nothing to exchange, the tokens come back as they are
+    from lkgd_amd.dist_run import ShardInfo
+    sh = ShardInfo(make_plan(2, 1, 6, cfg=True), None, entries=2)
+    x = torch.arange(2 * 6 * 4 * 3, dtype=torch.float32).reshape(-1, 3)
+    assert sh.gather(x) is x and sh.to_pixels(x, 4) is x and sh.to_frames(x, 4) is x and (sh.b0, sh.B_total) == (2, 4)
 
 
 def _free_port():
