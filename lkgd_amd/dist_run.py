@@ -226,7 +226,7 @@ class DistDenoiser:
                 if recorded is not None:
                     noise_local = recorded.run(ops.GEMM_EVENTS)
                 elif self.use_replay:
-                    with replay.record(self._arenas.take(dev)) as recorded:   # the first step runs for real and is recorded
+                    with replay.record(self._arenas.take(dev, (b_local, fl, H, W, ctrl_local is not None, id(unet._pk)))) as recorded:   # the first step runs for real and is recorded
                         recorded.result = forward()
                     noise_local = recorded.result
                 else:

@@ -317,7 +317,7 @@ class StableVideoDiffusionPipeline:
                     if recorded is not None:
                         noise_tok = recorded.run(ops.GEMM_EVENTS)
                     else:
-                        with _replay.record(self._arenas.take(dev)) as recorded:
+                        with _replay.record(self._arenas.take(dev, (cfg * B, F, H, W, ctrl is not None, id(unet._pk)))) as recorded:
                             recorded.result = forward_static()
                         noise_tok = recorded.result
                 else:

@@ -155,12 +155,19 @@ class ArenaSet:
     def __init__(self):
         self._arenas: List[Arena] = []
         self._lock = threading.Lock()
+        self._key = None
 
-    def take(self, device=None) -> Arena:
+    def take(self, device=None, key=None) -> Arena:
+        """``key``: what the recorded region's allocation pattern depends on (geometry, variant).  A pool caches blocks of the
+        sizes ITS forwards asked for; when the key changes the idle pools are dropped first, so that a caller who walks through
+        many resolutions does not accumulate one working set per resolution"""
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         with self._lock:
+            if key is not None and key != self._key:
+                self._arenas = [a for a in self._arenas if a.busy]
+                self._key = key
             for a in self._arenas:
                 if not a.busy and a.device == dev:
                     a.busy = True

@@ -258,7 +258,13 @@ def test_replay_arena_cold_caches_and_contract():
         s0 = float(pipe.scheduler.init_noise_sigma)
         outs[mode] = [pipe.denoise((lat0 * s0).half(), img, emb, ids, 3, 1.0, 3.0).clone() for _ in range(2)]
         if mode:
-            assert 0 < pipe.arena_reserved_bytes() < 600e6
+            first = pipe.arena_reserved_bytes()
+            assert 0 < first < 600e6
+            # another geometry on the same pipeline: the idle pool of the old one is dropped, not kept beside the new one
+            lat_s, img_s, emb_s, ids_s = bench.synthetic_inputs(dev, 4, 8, 8)
+            small = pipe.denoise((lat_s * s0).half(), img_s, emb_s, ids_s, 3, 1.0, 3.0)
+            assert torch.isfinite(small.float()).all() and len(pipe._arenas._arenas) == 1
+            assert pipe.arena_reserved_bytes() < first
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     x = torch.ones(4, 8, device=dev, dtype=torch.float16)
     with replay.strict(True):
