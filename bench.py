@@ -151,7 +151,9 @@ def cpu_baseline(args):
     whole workload of one Euler step: ~190 s on the GPU boxes seen so far) measured by THIS run in a CPU-only child process,
     x 25 steps / 14 frames.  Fallback (--no-cpu-full, or the guard fired): a bounded 1.19-TFLOP sample measured here beside
     the full-forward figure quoted from profiles/r02_cpu_full_forward.json, and the line says which it is."""
-    cores = torch.get_num_threads()
+    from tools.hostcpus import cpu_facts, host_cpus
+    cores = host_cpus()              # what this process can really run (cgroup quota / affinity), not os.cpu_count()
+    torch.set_num_threads(cores)
     if args.tiny:
         return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "tiny config (invalid)"}
     if not args.no_cpu_full:
@@ -161,7 +163,7 @@ def cpu_baseline(args):
             return {"value": round(fps_full, 6),
                     "unit": "frames/s (one full configs[1] UNet forward of the fp32 oracle, measured, x 25 steps / 14 frames)",
                     "cores": full.get("threads", cores), "kind": "port", "value_source": "measured by this run",
-                    "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
+                    "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": full.get("cgroup_cpu_quota"),
                     "sample": f"ONE full configs[1] forward (CFG 2 x {args.frames} frames x {args.height // 8}x{args.width // 8} latent, "
                               f"{UNET_TFLOP_C2:.2f} TFLOP) of the fp32 oracle (torch eager) in {float(full['seconds']):.1f} s = "
                               f"{full.get('tflops')} TFLOP/s on {full.get('threads', cores)} host threads, in a CPU-only child process "

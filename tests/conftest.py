@@ -13,6 +13,16 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 # moves device data outside a C-ABI launch / replay.step raises instead of going stale on replays (lkgd_amd/replay.py)
 os.environ.setdefault("LKGD_REPLAY_STRICT", "1")
 
+# the host side of the tests (the fp32 oracle) runs on the CPUs this process really has: a GPU box shows 256 logical CPUs behind a
+# cgroup quota of 16, and torch's default of 128 intra-op threads there is up to 30 x slower than 16 (tools/hostcpus.py).  Set
+# before torch starts its pool; rank processes the tests spawn inherit it and divide it among themselves (rank_threads()).
+from tools.hostcpus import host_cpus   # noqa: E402
+
+HOST_CPUS = host_cpus()
+os.environ.setdefault("OMP_NUM_THREADS", str(HOST_CPUS))
+os.environ.setdefault("MKL_NUM_THREADS", str(HOST_CPUS))
+os.environ["LKGD_TEST_HOST_CPUS"] = str(HOST_CPUS)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -73,7 +73,7 @@ def _build(dev):
 
 def _worker(rank, world, port, frames, guidance_on, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))   # the ranks share the box's host cores
+    torch.set_num_threads(max(1, int(os.environ.get("LKGD_TEST_HOST_CPUS", os.cpu_count() or 8)) // world))   # the ranks share the box's host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd.dist_run import DistDenoiser
@@ -109,7 +109,7 @@ def _worker_cn(rank, world, port, frames, q):
     """BASELINE.json configs[3]-style combination under sharding: the LKGD UNet (domain / flow features) with the
     ControlNet-SVD encoder in the loop (pipeline_stable_video_diffusion_controlnet.py:582-607)"""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))   # the ranks share the box's host cores
+    torch.set_num_threads(max(1, int(os.environ.get("LKGD_TEST_HOST_CPUS", os.cpu_count() or 8)) // world))   # the ranks share the box's host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd import controlnet as pc
@@ -150,7 +150,7 @@ def _worker_joint(rank, world, port, frames, q):
     `patch` joint-attention hooks on the spatial AND temporal blocks with masks [0,1,0,1] (utils/util.py:561-606,
     patch/patch.py:438-501,:616-658); a rank holds its frame slice of both clips of its CFG half"""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
+    torch.set_num_threads(max(1, int(os.environ.get("LKGD_TEST_HOST_CPUS", os.cpu_count() or 8)) // world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd import patch
@@ -195,7 +195,7 @@ def _worker_lora(rank, world, port, frames, q):
     single-process result, checked here again on rank 0).  A rank holds its frame slice of both clips of its CFG half: the
     per-entry weight variants apply to its two entries; the temporal blocks project them in the pixel-re-sharded layout."""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
+    torch.set_num_threads(max(1, int(os.environ.get("LKGD_TEST_HOST_CPUS", os.cpu_count() or 8)) // world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import test_lora as tl
@@ -273,7 +273,7 @@ def _worker_fsm(rank, world, port, frames, q):
     tracks, so the frame slices are cut at even frames (make_plan(frame_unit=2): 8 frames over 2 shards = (4, 4), 6 over 2 =
     (4, 2)) and each rank takes its pairs' rows of the track tables"""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
+    torch.set_num_threads(max(1, int(os.environ.get("LKGD_TEST_HOST_CPUS", os.cpu_count() or 8)) // world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd import patch_FSM
@@ -385,7 +385,7 @@ def test_sharded_controlnet_lk_loop_equals_single_process(world, frames):
 def _worker_dit(rank, world, port, q):
     """configs[4] under sharding: the CogVideoX DiT loop, CFG-parallel x latent-frame slices (3 latent frames over (2, 1))"""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))   # the ranks share the box's host cores
+    torch.set_num_threads(max(1, int(os.environ.get("LKGD_TEST_HOST_CPUS", os.cpu_count() or 8)) // world))   # the ranks share the box's host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd import cogvideox as pc

@@ -61,7 +61,7 @@ def _worker(rank, world, port, gpath, wpath, q):
     import time
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))   # the ranks share the box's host cores
+    torch.set_num_threads(max(1, int(os.environ.get("LKGD_TEST_HOST_CPUS", os.cpu_count() or 8)) // world))   # the ranks share the box's host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lkgd_amd import unet as pu

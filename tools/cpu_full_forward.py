@@ -14,6 +14,11 @@ sys.path.insert(0, REPO)
 import torch
 
 from oracle import unet as ou
+from tools.hostcpus import cpu_facts, host_cpus
+
+# the threads this process can really run (the pool's GPU boxes: a cgroup quota of 16 behind 256 logical CPUs; torch's default of
+# 128 intra-op threads is several times slower there).  LKGD_CPU_THREADS overrides.
+torch.set_num_threads(int(os.environ.get("LKGD_CPU_THREADS", host_cpus())))
 
 
 def run_full_forward(F=14, H=72, W=128, verbose=True):
@@ -60,7 +65,7 @@ def run_full_forward(F=14, H=72, W=128, verbose=True):
     tflop = 89.69 * (F / 14.0) * (H * W) / (72 * 128)          # algorithmic, SURVEY.md App. B (attention term scaled linearly: a bound)
     return {"workload": f"one UNet forward, CFG batch 2 x {F} frames x {H}x{W} latent, real-width SVD UNet, fp32 oracle (torch eager)",
             "seconds": round(dt, 1), "algorithmic_tflop": round(tflop, 2), "tflops": round(tflop / dt, 4),
-            "threads": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "finite": bool(torch.isfinite(y).all()),
+            "threads": torch.get_num_threads(), **cpu_facts(), "finite": bool(torch.isfinite(y).all()),
             "frames_per_s_c2_equivalent": round(14.0 / (25.0 * dt * (14.0 / F) * (72 * 128) / (H * W)), 6)}
 
 
