@@ -266,6 +266,22 @@ def test_replay_arena_cold_caches_and_contract():
             assert torch.isfinite(small.float()).all() and len(pipe._arenas._arenas) == 1
             assert pipe.arena_reserved_bytes() < first
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    # (c) ADVICE r5: whatever ends the Euler loop - here a callback's exception after the recorded step - the plan is released: its
+    # arena is idle again (no tens of GB waiting for the cycle collector) and the next call records and runs as if nothing happened
+    pipe = StableVideoDiffusionPipeline(unet=bench.build_unet(dev, tiny=True))
+    lat0, img, emb, ids = bench.synthetic_inputs(dev, 4, 16, 16)
+    pipe.scheduler.set_timesteps(3)
+    s0 = float(pipe.scheduler.init_noise_sigma)
+
+    def boom(p_, i, t, kw):
+        if i == 1:
+            raise RuntimeError("callback failed")
+        return kw
+    with pytest.raises(RuntimeError, match="callback failed"):
+        pipe.denoise((lat0 * s0).half(), img, emb, ids, 3, 1.0, 3.0, callback_on_step_end=boom)
+    assert ops.PLAN is None and all(not a.busy for a in pipe._arenas._arenas)
+    again = pipe.denoise((lat0 * s0).half(), img, emb, ids, 3, 1.0, 3.0)
+    assert torch.equal(again, outs[True][0]) and len(pipe._arenas._arenas) == 1
     x = torch.ones(4, 8, device=dev, dtype=torch.float16)
     with replay.strict(True):
         with pytest.raises(replay.ReplayContractError):
