@@ -105,7 +105,7 @@ def _worker(rank, world, port, frames, guidance_on, q):
         dist.destroy_process_group()
 
 
-def _worker_cn(rank, world, port, frames, q):
+def _worker_cn(rank, world, port, frames, q, nclips=1):
     """BASELINE.json configs[3]-style combination under sharding: the LKGD UNet (domain / flow features) with the
     ControlNet-SVD encoder in the loop (pipeline_stable_video_diffusion_controlnet.py:582-607)"""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -128,6 +128,14 @@ def _worker_cn(rank, world, port, frames, q):
         g = torch.Generator().manual_seed(78)
         ctrl = (2.0 * torch.rand(1, frames, 3, 64, 64, generator=g) - 1.0).repeat(2, 1, 1, 1, 1).half()
         dom, flow = torch.randn(1, 1, 1000, generator=g).half(), torch.randn(1, 1, 1000, generator=g).half()
+        if nclips == 2:            # round 6: several clips per ControlNet call, batch [u_1, u_2, c_1, c_2]; every rank takes its entries
+            lat0 = torch.cat([lat0, 0.9 * lat0.flip(1)])
+            img = torch.stack([img[0], img[0], img[1], 0.8 * img[1]])
+            emb = torch.stack([emb[0], emb[0], emb[1], 0.8 * emb[1]])
+            ids = ids[:1].repeat(4, 1)
+            c2 = (2.0 * torch.rand(1, frames, 3, 64, 64, generator=g) - 1.0).half()
+            ctrl = torch.cat([ctrl[:1], c2, ctrl[:1], c2])
+            dom, flow = torch.cat([dom, 0.7 * dom] * 2), torch.cat([flow, 0.6 * flow] * 2)
         pipe.scheduler.set_timesteps(2)
         s0 = float(pipe.scheduler.init_noise_sigma)
         runner = DistDenoiser(pipe, world, rank, frames, cfg=True)
@@ -361,12 +369,12 @@ def test_sharded_joint_pair_equals_single_process(world, frames):
         assert rel <= 8e-3, f"rank {r['rank']}: sharded joint pair vs single process: relative L2 {rel:.3e}"
 
 
-@pytest.mark.parametrize("world,frames", [(2, 4), (4, 5)])
-def test_sharded_controlnet_lk_loop_equals_single_process(world, frames):
+@pytest.mark.parametrize("world,frames,nclips", [(2, 4, 1), (4, 5, 1), (4, 4, 2)])
+def test_sharded_controlnet_lk_loop_equals_single_process(world, frames, nclips):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_cn, args=(r, world, port, frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_cn, args=(r, world, port, frames, q, nclips)) for r in range(world)]
     for p in procs:
         p.start()
     results = _collect(procs, q, world)
