@@ -65,10 +65,27 @@ class ShardPlan:
         return [c * self.frame_shards + self.shard_index for c in range(self.cfg_groups)]
 
 
-def split_frames(num_frames: int, shards: int, unit: int = 1) -> Tuple[int, ...]:
+def split_frames(num_frames: int, shards: int, unit: int = 1, symmetric: bool = False) -> Tuple[int, ...]:
     """contiguous, as even as possible, larger slices first: 14 over 4 -> (4, 4, 3, 3).  ``unit``: slices are cut at multiples of
     ``unit`` frames (2 with the FSM hook, which fuses frames 2k and 2k+1 - patch/patch_FSM.py:405-441: a pair must live on one
-    rank): 14 over 4 in pairs -> (4, 4, 4, 2)"""
+    rank): 14 over 4 in pairs -> (4, 4, 4, 2).  ``symmetric``: shard i and shard k-1-i hold equally many frames, so that frame f
+    and frame F-1-f sit at mirrored positions of mirrored shards (joint attention with flip=True, patch/patch.py:471-475):
+    14 over 4 -> (4, 3, 3, 4)"""
+    if symmetric:
+        if unit != 1:
+            raise ValueError("symmetric frame slices in groups of frames are not supported")
+        if shards < 1 or shards > num_frames:
+            raise ValueError(f"cannot split {num_frames} frames over {shards} shards")
+        q, r = divmod(num_frames, shards)
+        if r % 2 and shards % 2 == 0:
+            raise ValueError(f"{num_frames} frames do not split symmetrically over {shards} shards")
+        out = [q] * shards
+        for i in range(r // 2):                      # the extra frames go to the two ends, pairwise
+            out[i] += 1
+            out[shards - 1 - i] += 1
+        if r % 2:
+            out[shards // 2] += 1                    # ... and the odd one to the middle shard (its own mirror)
+        return tuple(out)
     if unit < 1 or num_frames % unit:
         raise ValueError(f"{num_frames} frames are not whole groups of {unit}")
     units = num_frames // unit
@@ -78,14 +95,14 @@ def split_frames(num_frames: int, shards: int, unit: int = 1) -> Tuple[int, ...]
     return tuple((q + 1 if i < r else q) * unit for i in range(shards))
 
 
-def make_plan(world: int, rank: int, num_frames: int, cfg: bool, frame_unit: int = 1) -> ShardPlan:
+def make_plan(world: int, rank: int, num_frames: int, cfg: bool, frame_unit: int = 1, symmetric: bool = False) -> ShardPlan:
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad world/rank")
     cfg_groups = 2 if (cfg and world >= 2) else 1
     if world % cfg_groups:
         raise ValueError(f"world size {world} must be even when classifier-free guidance is on")
     shards = world // cfg_groups
-    splits = split_frames(num_frames, shards, frame_unit)
+    splits = split_frames(num_frames, shards, frame_unit, symmetric)
     ci, si = divmod(rank, shards)
     return ShardPlan(world, rank, cfg_groups, shards, ci, si, splits, sum(splits[:si]), num_frames)
 
@@ -329,6 +346,24 @@ def exchange_halo(buf: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tenso
                 buf[fl + 1].copy_(hi)
     _step(step)
     return buf
+
+
+def exchange_with_mirror(x: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+    """x [rows, W] of this shard -> the [rows, W] tensor of the MIRROR shard k-1-i of the frame group (which receives ours).  The
+    slices must be symmetric (split_frames(symmetric=True)): both sides then hold equally many rows, and local frame t of a shard
+    mirrors local frame f_local-1-t of the other.  One all-to-all over the frame group whose only non-empty block is the mirror's
+    (a shard that is its own mirror - the middle one of an odd count - receives its own rows)."""
+    k, si = plan.frame_shards, plan.shard_index
+    if k == 1:
+        return x
+    if plan.splits[si] != plan.splits[k - 1 - si] or plan.f0 + plan.f_local != plan.num_frames - sum(plan.splits[:k - 1 - si]):
+        raise ValueError("exchange_with_mirror needs symmetric frame slices (make_plan(symmetric=True))")
+    if not x.is_contiguous() or x.dim() != 2:
+        raise ValueError("exchange_with_mirror needs a contiguous [rows, W] tensor")
+    recv = torch.empty_like(x)
+    rows = [x.shape[0] if r == k - 1 - si else 0 for r in range(k)]
+    _step(lambda: all_to_all_rows(recv, x, rows, rows, group))
+    return recv
 
 
 #: temporal GroupNorm + Conv3d halo of a frame-sharded rank in ONE collective (default): the raw boundary frames and the

@@ -28,8 +28,8 @@ import torch.distributed as dist
 
 from . import ops, replay
 from ._lib import LkgdHipError
-from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, frames_to_pixels, gather_boundary_frames_and_sums,
-                   gather_frames, make_plan, pixels_to_frames)
+from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, exchange_with_mirror, frames_to_pixels,
+                   gather_boundary_frames_and_sums, gather_frames, make_plan, pixels_to_frames)
 
 
 class ShardInfo:
@@ -98,6 +98,11 @@ class ShardInfo:
     def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
         return allreduce_sums(sums, self.plan, self.group)
 
+    def mirror(self, x: torch.Tensor) -> torch.Tensor:
+        """[rows, W] of this shard <-> the same-shaped tensor of the mirror shard (joint attention with flip=True: frame f of an
+        entry attends to frame F-1-f of its partner, which the mirror shard holds at local position f_local-1-t)"""
+        return exchange_with_mirror(x, self.plan, self.group)
+
     def halo_raw(self, first, last, sums: torch.Tensor) -> torch.Tensor:
         """the raw boundary frames and the GroupNorm partial sums of every entry in one all-gather (lkgd_amd/dist.py)"""
         return gather_boundary_frames_and_sums(first, last, sums, self.plan, self.group)
@@ -119,7 +124,13 @@ class DistDenoiser:
         self.pipe = pipe
         # the FSM hook (lkgd_amd/patch_FSM.py) fuses frames 2k and 2k+1 of a clip: frame slices are then cut at even frames
         fsm = any(getattr(m, "_lkgd_fsm", False) for m in pipe.unet.modules())
-        self.plan = make_plan(world, rank, num_frames, cfg, frame_unit=2 if (fsm and world > (2 if cfg else 1)) else 1)
+        # joint attention with flip=True (patch.apply_patch(flip=True): checkpoints trained with it, utils/util.py:541-561) pairs frame f
+        # with frame F-1-f of the partner clip: the frame slices are then symmetric - 14 over 4 = (4,3,3,4) - and every spatial joint
+        # block trades its K | V rows with the mirror shard (ShardInfo.mirror)
+        info = getattr(pipe.unet, "_tome_info", None)
+        flip = bool(info and info.get("args", {}).get("flip", False)) and not fsm
+        sharded = world > (2 if cfg else 1)
+        self.plan = make_plan(world, rank, num_frames, cfg, frame_unit=2 if (fsm and sharded) else 1, symmetric=flip and sharded)
         # every rank creates every group, in the same order
         self.frame_group = None
         for c in range(self.plan.cfg_groups):

@@ -103,6 +103,7 @@ class Ctx:
         # multi-token context (Lk > 1): the literal attn2 path (_cross_literal); xb_all is then a table of zeros
         self.cross_Lk = 1
         self.cross_e: Optional[torch.Tensor] = None       # [B_total * Lk, cross_attention_dim] fp16
+        self.flip_mirror = False       # flip=True joint attention on a frame-sharded rank: K | V of attn1n come from the mirror shard
 
     @property
     def frames_sharded(self) -> bool:
@@ -471,8 +472,17 @@ class BasicTransformerBlock(nn.Module):
             vj = [_attn_variant(self, "a1n", ctx, i, True) for i in range(len(ctx.lora.runs))]
             _gemm_runs(ctx, ln, qkv, lambda i: (vj[i].wqkv, vj[i].bqkv, None), N=3 * Cc, K=Cc)
         att = ctx.new(T, Cc)
-        ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, self.attn1n.heads,
-                         kv_batch_map=ctx.spatial_partner)
+        kk, vv = qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+        if ctx.flip_mirror:
+            # the partner's frame F-1-f lives on the mirror shard: trade the K | V rows of this block with it (one all-to-all whose
+            # only block is the mirror's).  The projections - also the partner-side LoRA variants - were computed where the rows live
+            from . import dist as _dist
+            kv_own = ctx.new(T, 2 * Cc)
+            src = qkv[:, Cc:]
+            _dist._step(lambda: kv_own.copy_(src))
+            kv_mirror = ctx.shard.mirror(kv_own)
+            kk, vv = kv_mirror[:, :Cc], kv_mirror[:, Cc:]
+        ops.attn_spatial(qkv[:, :Cc], kk, vv, att, ctx.N, ctx.HW, self.attn1n.heads, kv_batch_map=ctx.spatial_partner)
         out = ctx.new(T, Cc)
         js = float(self.joint_scale)
         if pk.post != "conv_fuse":
@@ -1401,9 +1411,15 @@ class _UNetBase(nn.Module):
                 raise LkgdHipError("joint attention under sharding: a rank's batch entries must hold whole (masked, unmasked) "
                                    f"pairs; mask {full}, entries {ctx.b0}..{ctx.b0 + ctx.B - 1}")
             if flip and ctx.frames_sharded:
-                raise LkgdHipError("joint attention with flip=True pairs frame f with frame F-1-f of the partner clip, which "
-                                   "lives on another rank under frame sharding: run flip=True on one GPU or on the CFG-parallel "
-                                   "layout (2 GPUs), where a rank holds all frames of both clips")
+                # frame f of an entry attends to frame F-1-f of its partner: on the MIRROR shard, at local position f_local-1-t when
+                # the slices are symmetric.  The spatial joint block then reads its K | V rows from the mirror shard's buffer
+                # (BasicTransformerBlock._joint), and the partner map below - built on LOCAL frame counts - indexes that buffer
+                pl = ctx.shard.plan
+                k_, si_ = pl.frame_shards, pl.shard_index
+                if pl.splits[si_] != pl.splits[k_ - 1 - si_] or pl.f0 + pl.f_local != pl.num_frames - sum(pl.splits[:k_ - 1 - si_]):
+                    raise LkgdHipError("joint attention with flip=True under frame sharding needs symmetric frame slices "
+                                       f"(dist.make_plan(symmetric=True)); this plan's are {pl.splits}")
+                ctx.flip_mirror = True
             mask = own
 
         def partner(n_rows, group):

@@ -40,6 +40,11 @@ def test_split_and_plans():
         split_frames(14, 8, 2)                 # more shards than pairs
     with pytest.raises(ValueError):
         split_frames(13, 2, 2)                 # an odd clip has no whole pairs
+    # ... and symmetric slices for flip=True joint attention: shard i and k-1-i mirror each other frame for frame
+    assert split_frames(14, 4, symmetric=True) == (4, 3, 3, 4) and split_frames(7, 3, symmetric=True) == (2, 3, 2)
+    assert split_frames(6, 4, symmetric=True) == (2, 1, 1, 2) and split_frames(14, 2, symmetric=True) == (7, 7)
+    with pytest.raises(ValueError):
+        split_frames(5, 2, symmetric=True)
     p = make_plan(8, 7, 14, cfg=True, frame_unit=2)
     assert p.splits == (4, 4, 4, 2) and p.f0 == 12 and p.f_local == 2 and all(s % 2 == 0 for s in p.splits)
     # one frame slice (pure CFG-parallel) with several entries per rank: nothing to exchange, the tokens come back as they are
@@ -266,6 +271,56 @@ def _worker_replay_entries(rank, world, port, frames, q):
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_mirror(rank, world, port, frames, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lkgd_amd import replay
+        from lkgd_amd.dist import exchange_with_mirror
+        plan = make_plan(world, rank, frames, cfg=False, symmetric=True)
+        mp_ = make_plan(world, world - 1 - rank, frames, cfg=False, symmetric=True)
+        ok = plan.f_local == mp_.f_local
+        HW, W = 3, 4
+        full = torch.arange(frames * HW * W, dtype=torch.float32).reshape(frames, HW, W) + 1.0
+        mine = full[plan.f0:plan.f0 + plan.f_local].reshape(-1, W).clone()
+        with replay.record() as rec:
+            got = exchange_with_mirror(mine, plan)
+        for scale in (1.0, -2.0):
+            if scale != 1.0:
+                mine.copy_(scale * full[plan.f0:plan.f0 + plan.f_local].reshape(-1, W))
+                rec.run()
+            ok = ok and torch.equal(got, scale * full[mp_.f0:mp_.f0 + mp_.f_local].reshape(-1, W))
+            # local frame t of the mirror shard is global frame F-1-(f0 + f_local-1-t): the flip of patch/patch.py:471-475
+            t = 0
+            ok = ok and torch.equal(got.reshape(plan.f_local, HW, W)[plan.f_local - 1 - t], scale * full[frames - 1 - (plan.f0 + t)])
+        bad = make_plan(world, rank, frames, cfg=False)            # (3, 3, 2, 2)-style slices are not mirror images of each other
+        if bad.splits != plan.splits:
+            try:
+                exchange_with_mirror(mine, bad)
+                ok = False
+            except ValueError:
+                pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames", [(4, 6), (3, 7), (2, 6)])
+def test_mirror_exchange_of_symmetric_slices(world, frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mirror, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]
 
 
 @pytest.mark.parametrize("world,frames", [(2, 5), (4, 6)])

@@ -153,7 +153,7 @@ def _worker_cn(rank, world, port, frames, q, nclips=1):
         dist.destroy_process_group()
 
 
-def _worker_joint(rank, world, port, frames, q):
+def _worker_joint(rank, world, port, frames, q, flip=False):
     """the [start, end] pair of the trans pipelines under sharding (round 5): TWO clips per call, UNet batch [u_x, u_y, c_x, c_y],
     `patch` joint-attention hooks on the spatial AND temporal blocks with masks [0,1,0,1] (utils/util.py:561-606,
     patch/patch.py:438-501,:616-658); a rank holds its frame slice of both clips of its CFG half"""
@@ -167,7 +167,7 @@ def _worker_joint(rank, world, port, frames, q):
         dev = torch.device("cuda", 0)
         unet = _build(dev)
         pipe = StableVideoDiffusionPipeline(unet=unet)
-        patch.apply_patch(pipe, with_temporal_block=True)
+        patch.apply_patch(pipe, with_temporal_block=True, flip=flip)
         patch.initialize_joint_layers(pipe)
         with torch.no_grad():                      # zero-initialised joint layers would be an identity branch
             g = torch.Generator().manual_seed(12350)
@@ -177,7 +177,7 @@ def _worker_joint(rank, world, port, frames, q):
         unet.invalidate()
         patch.set_joint_attention_mask(pipe, [0, 1, 0, 1])
         lat0, img, emb, ids = _inputs(frames, True)
-        lat0 = torch.cat([lat0, 0.9 * lat0.flip(1)])                         # two clips
+        lat0 = torch.cat([lat0, 0.9 * lat0.flip(1) + 0.3 * torch.randn(lat0.shape, generator=g)])      # two clips
         img = torch.stack([img[0], img[0], img[1], 0.8 * img[1]])            # [u_x, u_y, c_x, c_y]
         emb = torch.stack([emb[0], emb[0], emb[1], 0.8 * emb[1]])
         ids = ids[:1].repeat(4, 1)
@@ -186,9 +186,12 @@ def _worker_joint(rank, world, port, frames, q):
         runner = DistDenoiser(pipe, world, rank, frames, cfg=True)
         args = lambda: ((lat0 * s0).half().to(dev), img.half().to(dev), emb.half().to(dev), ids.to(dev), 2, 1.0, 3.0)   # noqa: E731
         out = runner.denoise(*args())
-        res = {"rank": rank, "out": out.float().cpu()}
+        res = {"rank": rank, "out": out.float().cpu(), "splits": list(runner.plan.splits)}
         if rank == 0:
             res["ref"] = pipe.denoise(*args()).float().cpu()
+            if flip:                                         # ... and the frame reversal must matter to it
+                unet._tome_info["args"]["flip"] = False
+                res["noflip"] = pipe.denoise(*args()).float().cpu()
             patch.remove_patch(pipe)                         # the hooks off: the joint branch must matter to the result
             res["plain"] = pipe.denoise(*args()).float().cpu()
         q.put(_ship(res))
@@ -345,15 +348,17 @@ def test_sharded_fsm_hook_equals_single_process(world, frames, splits):
         assert rel <= 8e-3, f"rank {r['rank']}: sharded FSM hook vs single process: relative L2 {rel:.3e}"
 
 
-@pytest.mark.parametrize("world,frames", [(2, 4), (4, 5)])
-def test_sharded_joint_pair_equals_single_process(world, frames):
+@pytest.mark.parametrize("world,frames,flip", [(2, 4, False), (4, 5, False), (4, 6, True), (6, 7, True)])
+def test_sharded_joint_pair_equals_single_process(world, frames, flip):
     """2 ranks: CFG halves x 2 clips each (the joint pairs are local, no frame exchange); 4 ranks: CFG x frame slices (3, 2) of
     both clips - temporal GroupNorm sums, Conv3d halos and the pixel re-sharding run entry by entry, the temporal joint branch
-    runs in the re-sharded layout"""
+    runs in the re-sharded layout.  ``flip`` (round 6; patch.apply_patch(flip=True), patch/patch.py:471-475): frame f attends to
+    frame F-1-f of the partner clip - symmetric slices (4 ranks: (3, 3); 6 ranks: CFG x (2, 3, 2), the middle shard its own mirror)
+    and one K | V exchange with the mirror shard per spatial joint block"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_joint, args=(r, world, port, frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_joint, args=(r, world, port, frames, q, flip)) for r in range(world)]
     for p in procs:
         p.start()
     results = _collect(procs, q, world)
@@ -364,6 +369,9 @@ def test_sharded_joint_pair_equals_single_process(world, frames):
     ref = r0["ref"]
     assert ref.shape[0] == 2 and torch.isfinite(ref).all()
     assert ((r0["plain"] - ref).norm() / ref.norm()).item() > 2e-2      # the joint branches really enter
+    if flip:
+        assert ((r0["noflip"] - ref).norm() / ref.norm()).item() > 5e-3  # ... and so does the frame reversal
+        assert r0["splits"] == list(reversed(r0["splits"]))
     for r in results:
         rel = ((r["out"] - ref).norm() / ref.norm()).item()
         assert rel <= 8e-3, f"rank {r['rank']}: sharded joint pair vs single process: relative L2 {rel:.3e}"
