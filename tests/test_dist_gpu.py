@@ -348,13 +348,13 @@ def test_sharded_fsm_hook_equals_single_process(world, frames, splits):
         assert rel <= 8e-3, f"rank {r['rank']}: sharded FSM hook vs single process: relative L2 {rel:.3e}"
 
 
-@pytest.mark.parametrize("world,frames,flip", [(2, 4, False), (4, 5, False), (4, 6, True), (6, 7, True)])
+@pytest.mark.parametrize("world,frames,flip", [(2, 4, False), (4, 5, False), (4, 6, True)])
 def test_sharded_joint_pair_equals_single_process(world, frames, flip):
     """2 ranks: CFG halves x 2 clips each (the joint pairs are local, no frame exchange); 4 ranks: CFG x frame slices (3, 2) of
     both clips - temporal GroupNorm sums, Conv3d halos and the pixel re-sharding run entry by entry, the temporal joint branch
     runs in the re-sharded layout.  ``flip`` (round 6; patch.apply_patch(flip=True), patch/patch.py:471-475): frame f attends to
-    frame F-1-f of the partner clip - symmetric slices (4 ranks: (3, 3); 6 ranks: CFG x (2, 3, 2), the middle shard its own mirror)
-    and one K | V exchange with the mirror shard per spatial joint block"""
+    frame F-1-f of the partner clip - symmetric slices (4 ranks: CFG x (3, 3); an odd shard count, whose middle shard is its own mirror, is
+    covered on the CPU: the pool allows six GPU processes, pytest included) and one K | V exchange with the mirror shard per spatial joint block"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
