@@ -348,21 +348,48 @@ def exchange_halo(buf: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tenso
     return buf
 
 
-def exchange_with_mirror(x: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
-    """x [rows, W] of this shard -> the [rows, W] tensor of the MIRROR shard k-1-i of the frame group (which receives ours).  The
-    slices must be symmetric (split_frames(symmetric=True)): both sides then hold equally many rows, and local frame t of a shard
-    mirrors local frame f_local-1-t of the other.  One all-to-all over the frame group whose only non-empty block is the mirror's
-    (a shard that is its own mirror - the middle one of an odd count - receives its own rows)."""
+def exchange_with_mirror_start(x: torch.Tensor, plan: ShardPlan, group=None):
+    """x [rows, W] of this shard -> (recv, finish): recv will hold the [rows, W] tensor of the MIRROR shard k-1-i of the frame group
+    (which receives ours) once ``finish()`` has run.  The slices must be symmetric (split_frames(symmetric=True)): both sides then
+    hold equally many rows, and local frame t of a shard mirrors local frame f_local-1-t of the other.  One all-to-all over the frame
+    group whose only non-empty block is the mirror's (a shard that is its own mirror - the middle one of an odd count - receives its
+    own rows).
+
+    This is the one exchange of the sharded forward whose consumer is NOT the next op: the K | V rows of a spatial joint block are
+    read by attn1n's attention only, and the block's main branch (QKV, attention, out-projection) stands between.  With RCCL the
+    all-to-all is therefore ISSUED here as an asynchronous operation - the communicator's own stream waits for the launch stream
+    at this point and the transfer runs beside the kernels enqueued afterwards - and ``finish()`` makes the launch stream wait for
+    it right before the first reader.  Both halves are replay steps (lkgd_amd/replay.py).  With gloo (tests; device tensors staged
+    through host memory) the exchange completes inside the start step and finish() is empty."""
     k, si = plan.frame_shards, plan.shard_index
     if k == 1:
-        return x
+        return x, (lambda: None)
     if plan.splits[si] != plan.splits[k - 1 - si] or plan.f0 + plan.f_local != plan.num_frames - sum(plan.splits[:k - 1 - si]):
         raise ValueError("exchange_with_mirror needs symmetric frame slices (make_plan(symmetric=True))")
     if not x.is_contiguous() or x.dim() != 2:
         raise ValueError("exchange_with_mirror needs a contiguous [rows, W] tensor")
     recv = torch.empty_like(x)
     rows = [x.shape[0] if r == k - 1 - si else 0 for r in range(k)]
-    _step(lambda: all_to_all_rows(recv, x, rows, rows, group))
+    side = _backend(group) == "nccl" and x.is_cuda
+    pending = []
+
+    def issue():
+        if side:
+            pending.append(dist.all_to_all_single(recv, x, rows, rows, group=group, async_op=True))
+        else:
+            all_to_all_rows(recv, x, rows, rows, group)
+
+    def wait():
+        while pending:
+            pending.pop().wait()          # the launch stream waits for the communicator's stream; the host does not block
+    _step(issue)
+    return recv, (lambda: _step(wait))
+
+
+def exchange_with_mirror(x: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+    """exchange_with_mirror_start + finish at once"""
+    recv, finish = exchange_with_mirror_start(x, plan, group)
+    finish()
     return recv
 
 

@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from . import ops, replay
 from ._lib import LkgdHipError
-from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, exchange_with_mirror, frames_to_pixels,
+from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, exchange_with_mirror_start, frames_to_pixels,
                    gather_boundary_frames_and_sums, gather_frames, make_plan, pixels_to_frames)
 
 
@@ -98,10 +98,11 @@ class ShardInfo:
     def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
         return allreduce_sums(sums, self.plan, self.group)
 
-    def mirror(self, x: torch.Tensor) -> torch.Tensor:
+    def mirror_start(self, x: torch.Tensor):
         """[rows, W] of this shard <-> the same-shaped tensor of the mirror shard (joint attention with flip=True: frame f of an
-        entry attends to frame F-1-f of its partner, which the mirror shard holds at local position f_local-1-t)"""
-        return exchange_with_mirror(x, self.plan, self.group)
+        entry attends to frame F-1-f of its partner, which the mirror shard holds at local position f_local-1-t).  Returns
+        (recv, finish): issued now, finish() before the first read (lkgd_amd/dist.py::exchange_with_mirror_start)"""
+        return exchange_with_mirror_start(x, self.plan, self.group)
 
     def halo_raw(self, first, last, sums: torch.Tensor) -> torch.Tensor:
         """the raw boundary frames and the GroupNorm partial sums of every entry in one all-gather (lkgd_amd/dist.py)"""

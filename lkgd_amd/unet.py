@@ -429,6 +429,10 @@ class BasicTransformerBlock(nn.Module):
         else:
             va = [_attn_variant(self, "a1", ctx, i, True) for i in range(len(ctx.lora.runs))]
             _gemm_runs(ctx, ln, qkv, lambda i: (va[i].wqkv, va[i].bqkv, None), N=3 * Cc, K=Cc)
+        # flip=True joint attention on a frame-sharded rank: attn1n's K | V rows come from the mirror shard.  Its projection runs FIRST
+        # and the exchange is issued here, so that it travels under this branch's attention and out-projection (the one place of the
+        # sharded forward where an exchange's consumer is not the very next op)
+        pre = self._joint_start(ctx, ln) if (joint and ctx.flip_mirror) else None
         att = ctx.new(T, Cc)
         ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, ctx.N, ctx.HW, heads)
         h1 = ctx.new(T, Cc)
@@ -438,7 +442,7 @@ class BasicTransformerBlock(nn.Module):
             _gemm_runs(ctx, att, h1, lambda i: (va[i].wo, va[i].bo, ctx.xb_runs[i][ctx.b0:, pk.xoff:pk.xoff + Cc]),
                        N=Cc, K=Cc, rowmap=ops.rowmap_div(ctx.F * ctx.HW), res1=h)
             if self.enable_joint_attention and hasattr(self, "attn1n"):
-                h1 = self._joint(ctx, ln, h1)
+                h1 = self._joint(ctx, ln, h1, pre)
             return self._tail(ctx, h1)
         if getattr(self, "_lkgd_fsm", False) and self.enable_joint_attention:
             # the track fuse reads attn1(x) + x BEFORE cross-attention: the folded attn2 bias is added by its last kernels
@@ -448,7 +452,7 @@ class BasicTransformerBlock(nn.Module):
         ops.gemm(att, pk.a1.wo, h1, M=T, N=Cc, K=Cc, bias=pk.a1.bo, res1=h,
                  rowbias=ctx.xb_all[ctx.b0:, pk.xoff:pk.xoff + Cc], rowmap=ops.rowmap_div(ctx.F * ctx.HW))
         if self.enable_joint_attention and hasattr(self, "attn1n"):
-            h1 = self._joint(ctx, ln, h1)
+            h1 = self._joint(ctx, ln, h1, pre)
         return self._tail(ctx, h1)
 
     def _tail(self, ctx: Ctx, h1: torch.Tensor) -> torch.Tensor:
@@ -457,10 +461,9 @@ class BasicTransformerBlock(nn.Module):
             h1 = _cross_literal(self, ctx, h1, ops.rowmap_div(ctx.F * ctx.HW), ctx.b0)
         return _ff_ln(ctx, self._pk.ff, h1)
 
-    def _joint(self, ctx: Ctx, ln: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
-        """joint attention attn1n with the partner batch entry's K/V (patch/patch.py:438-501); the post step
-        (conv1n / scale1n / conv_fuse) is folded into the out-projection, so the branch ends in ONE GEMM epilogue
-        h1 + joint_scale * post(attn1n(...))"""
+    def _joint_start(self, ctx: Ctx, ln: torch.Tensor):
+        """Q | K | V of attn1n (per-entry LoRA variants where the model carries them); on a flip=True frame-sharded rank also the
+        start of the K | V exchange with the mirror shard.  Returns (qkv, vj, k, v, finish)"""
         pk, T, Cc = self._pk, ln.shape[0], ln.shape[1]
         if ctx.spatial_partner is None:
             raise LkgdHipError("joint attention enabled but no joint_attn_mask set (patch.set_joint_attention_mask)")
@@ -471,8 +474,7 @@ class BasicTransformerBlock(nn.Module):
         else:
             vj = [_attn_variant(self, "a1n", ctx, i, True) for i in range(len(ctx.lora.runs))]
             _gemm_runs(ctx, ln, qkv, lambda i: (vj[i].wqkv, vj[i].bqkv, None), N=3 * Cc, K=Cc)
-        att = ctx.new(T, Cc)
-        kk, vv = qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+        kk, vv, finish = qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], None
         if ctx.flip_mirror:
             # the partner's frame F-1-f lives on the mirror shard: trade the K | V rows of this block with it (one all-to-all whose
             # only block is the mirror's).  The projections - also the partner-side LoRA variants - were computed where the rows live
@@ -480,8 +482,19 @@ class BasicTransformerBlock(nn.Module):
             kv_own = ctx.new(T, 2 * Cc)
             src = qkv[:, Cc:]
             _dist._step(lambda: kv_own.copy_(src))
-            kv_mirror = ctx.shard.mirror(kv_own)
+            kv_mirror, finish = ctx.shard.mirror_start(kv_own)
             kk, vv = kv_mirror[:, :Cc], kv_mirror[:, Cc:]
+        return qkv, vj, kk, vv, finish
+
+    def _joint(self, ctx: Ctx, ln: torch.Tensor, h1: torch.Tensor, pre=None) -> torch.Tensor:
+        """joint attention attn1n with the partner batch entry's K/V (patch/patch.py:438-501); the post step
+        (conv1n / scale1n / conv_fuse) is folded into the out-projection, so the branch ends in ONE GEMM epilogue
+        h1 + joint_scale * post(attn1n(...)).  ``pre``: what _joint_start returned when run() called it ahead of the main branch"""
+        pk, T, Cc = self._pk, ln.shape[0], ln.shape[1]
+        qkv, vj, kk, vv, finish = pre if pre is not None else self._joint_start(ctx, ln)
+        if finish is not None:
+            finish()                   # the mirror shard's K | V have arrived (the launch stream waits for the exchange here)
+        att = ctx.new(T, Cc)
         ops.attn_spatial(qkv[:, :Cc], kk, vv, att, ctx.N, ctx.HW, self.attn1n.heads, kv_batch_map=ctx.spatial_partner)
         out = ctx.new(T, Cc)
         js = float(self.joint_scale)
