@@ -251,15 +251,19 @@ def frames_to_pixels(local: torch.Tensor, plan: ShardPlan, group=None, out: Opti
     return recv.view(plan.num_frames, px[si], C)
 
 
-def pixels_to_frames(x: torch.Tensor, plan: ShardPlan, HW: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """inverse of frames_to_pixels: x [F, px_local, C] -> [f_local, HW, C]"""
+def pixels_to_frames_start(x: torch.Tensor, plan: ShardPlan, HW: int, group=None, out: Optional[torch.Tensor] = None):
+    """inverse of frames_to_pixels, in two halves: x [F, px_local, C] -> (result [f_local, HW, C], finish).  The all-to-all is issued
+    here - with RCCL as an asynchronous operation on the communicator's stream, which waits for the launch stream at this point -
+    and ``finish()`` (the wait + the unpack of the received rows) must run before the result is read.  Whatever the caller enqueues
+    in between runs beside the transfer: the temporal block's joint branch beside the main branch's attention output, the main
+    out-projection beside the joint branch's (lkgd_amd/unet.py).  Both halves are replay steps."""
     k, si = plan.frame_shards, plan.shard_index
     if k == 1:
         if out is None:
-            return x
+            return x, (lambda: None)
         dst = _dest(out, tuple(x.shape), x)
         _step(lambda: dst.copy_(x))
-        return dst
+        return dst, (lambda: None)
     F, pl, C = x.shape
     px = pixel_splits(HW, k)
     if F != plan.num_frames or pl != px[si] or not x.is_contiguous():
@@ -275,19 +279,34 @@ def pixels_to_frames(x: torch.Tensor, plan: ShardPlan, HW: int, group=None, out:
         pieces.append((out[:, p0[r]:p0[r] + px[r], :], recv[o:o + out_rows[r]].view(fl, px[r], C)))
         o += out_rows[r]
     flat = x.view(F * pl, C)
-
     one_launch = _hip_rows(x, C)
+    side = _backend(group) == "nccl" and x.is_cuda
+    pending = []
 
-    def step():
-        all_to_all_rows(recv, flat, out_rows, in_rows, group)
+    def issue():
+        if side:
+            pending.append(dist.all_to_all_single(recv, flat, out_rows, in_rows, group=group, async_op=True))
+        else:
+            all_to_all_rows(recv, flat, out_rows, in_rows, group)
+
+    def wait_and_unpack():
+        while pending:
+            pending.pop().wait()          # the launch stream waits for the communicator's stream; the host does not block
         if one_launch:
             from . import ops
             ops.shard_rows(recv, out, fl, HW, C, px, False)
         else:
             for dst, src in pieces:
                 dst.copy_(src)
-    _step(step)
-    return out
+    _step(issue)
+    return out, (lambda: _step(wait_and_unpack))
+
+
+def pixels_to_frames(x: torch.Tensor, plan: ShardPlan, HW: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """inverse of frames_to_pixels: x [F, px_local, C] -> [f_local, HW, C] (issued and finished at once)"""
+    res, finish = pixels_to_frames_start(x, plan, HW, group, out)
+    finish()
+    return res
 
 
 def exchange_halo(buf: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:

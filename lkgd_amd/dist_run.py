@@ -29,7 +29,7 @@ import torch.distributed as dist
 from . import ops, replay
 from ._lib import LkgdHipError
 from .dist import (ShardPlan, all_gather_into, allreduce_sums, exchange_halo, exchange_with_mirror_start, frames_to_pixels,
-                   gather_boundary_frames_and_sums, gather_frames, make_plan, pixels_to_frames)
+                   gather_boundary_frames_and_sums, gather_frames, make_plan, pixels_to_frames, pixels_to_frames_start)
 
 
 class ShardInfo:
@@ -94,6 +94,26 @@ class ShardInfo:
             return pixels_to_frames(t.reshape(F, t.shape[0] // F, t.shape[-1]), self.plan, HW, self.group,
                                     out=out).reshape(-1, t.shape[-1])
         return self._per_entry(x, one, self.plan.f_local * HW)
+
+    def to_frames_start(self, x: torch.Tensor, HW: int):
+        """to_frames in two halves: (result, finish) - every entry's all-to-all is issued now, finish() (waits + unpacks) before the
+        result is read (lkgd_amd/dist.py::pixels_to_frames_start)"""
+        if self.plan.frame_shards == 1:
+            return x, (lambda: None)
+        F, n = self.plan.num_frames, self.entries
+        rows, rows_out = x.shape[0] // n, self.plan.f_local * HW
+        out = torch.empty(n * rows_out, x.shape[-1], dtype=x.dtype, device=x.device)
+        fins = []
+        for e in range(n):
+            t = x[e * rows:(e + 1) * rows]
+            _, fin = pixels_to_frames_start(t.reshape(F, t.shape[0] // F, t.shape[-1]), self.plan, HW, self.group,
+                                            out=out[e * rows_out:(e + 1) * rows_out])
+            fins.append(fin)
+
+        def finish():
+            for f in fins:
+                f()
+        return out, finish
 
     def allreduce(self, sums: torch.Tensor) -> torch.Tensor:
         return allreduce_sums(sums, self.plan, self.group)

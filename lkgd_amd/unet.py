@@ -593,6 +593,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         att = ctx.new(T, Cc)
         va = None
         att_joint = None       # attn1n's attention output where the sharded paths below compute it (frames on several GPUs)
+        fin_att = fin_joint = None     # pending halves of the re-sharding exchanges that bring attention outputs back to frame slices
         # LayerNorm + QKV + attention over the frames in one kernel where it exists (C = 320: the 72x128 level); the joint
         # branch reads the normalised tokens again, masked LoRA runs per-entry weights, a sharded rank gathers frames: unfused
         joint = self.enable_joint_attention and hasattr(self, "attn1n")
@@ -663,7 +664,9 @@ class TemporalBasicTransformerBlock(nn.Module):
                 qkv = ctx.new(Tp, 3 * Cc)
                 ops.gemm(ln1p, pk.a1.wqkv, qkv, M=Tp, N=3 * Cc, K=Cc, bias=pk.a1.bqkv)
                 ops.attn_temporal(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], attp, ctx.B, Ft, pxl, self.attn1.heads)
-            att = ctx.shard.to_frames(attp, ctx.HW)
+            # the attention output goes back to frame slices: issued here, awaited right before the out-projection reads it - with the
+            # joint branch on, that branch's projection and attention run beside the transfer (RCCL: an asynchronous all-to-all)
+            att, fin_att = ctx.shard.to_frames_start(attp, ctx.HW)
             if joint:
                 # the joint branch in the same pixel layout: all frames of the partner ENTRY's pixels are on this rank (a rank
                 # holds its slice of every clip of its CFG half), so attn1n needs no exchange beyond bringing its output back
@@ -679,7 +682,7 @@ class TemporalBasicTransformerBlock(nn.Module):
                     _gemm_runs(ctx, ln1p, qkvj, lambda i: (vjp[i].wqkv, vjp[i].bqkv, None), N=3 * Cc, K=Cc, rows=Ft * pxl)
                 ops.attn_temporal(qkvj[:, :Cc], qkvj[:, Cc:2 * Cc], qkvj[:, 2 * Cc:], attjp, ctx.B, Ft, pxl, self.attn1n.heads,
                                   kv_b_map=ctx.temporal_partner)
-                att_joint = ctx.shard.to_frames(attjp, ctx.HW)
+                att_joint, fin_joint = ctx.shard.to_frames_start(attjp, ctx.HW)    # ... and this one beside the main out-projection
         else:
             # LKGD_TEMPORAL_GATHER=1: local queries against the keys / values of ALL frames.  The
             # normalised hidden states are gathered (C channels) and K|V projected here for every frame: half the
@@ -722,6 +725,8 @@ class TemporalBasicTransformerBlock(nn.Module):
         else:
             raise ValueError(order)
         m2 = ctx.new(T, Cc)
+        if fin_att is not None:
+            fin_att()
         if one_launch:
             if getattr(pk.a1, "wblock", None) is None:
                 from .packing import pack_tblock
@@ -734,6 +739,8 @@ class TemporalBasicTransformerBlock(nn.Module):
             b_off = ctx.b0 if order == "batch_major" else 0
             _gemm_runs(ctx, att, m2, lambda i: (va[i].wo, va[i].bo, ctx.xb_runs[i][b_off:, pk.xoff:pk.xoff + Cc]),
                        N=Cc, K=Cc, rowmap=xmap, res1=m1)
+        if fin_joint is not None:
+            fin_joint()
         if self.enable_joint_attention and hasattr(self, "attn1n"):
             m2 = self._joint(ctx, ln1, m2, att_joint)
         if ctx.cross_Lk > 1:                  # literal attn2 over the time context (same row -> context map as the folded bias)
