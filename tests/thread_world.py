@@ -76,7 +76,7 @@ class ThreadWorld:
             out[p * n:(p + 1) * n].copy_(t)
         g.barrier.wait()
 
-    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
         g, i = self._enter(group, (inp, list(input_split_sizes)))
         o = 0
         for p, (pinp, prow) in enumerate(g.slots):
@@ -85,6 +85,8 @@ class ThreadWorld:
             out[o:o + n].copy_(pinp[start:start + n])
             o += n
         g.barrier.wait()
+        if async_op:            # the issue / wait split of lkgd_amd.dist (asynchronous with RCCL): here the copies are enqueued on the
+            return _Done()      # one shared stream at the issue point, so the "work" has nothing left to wait for
 
     def all_reduce(self, t, op=ReduceOp.SUM, group=None):
         assert op == ReduceOp.SUM
@@ -94,6 +96,13 @@ class ThreadWorld:
             acc += s
         g.barrier.wait()
         t.copy_(acc)
+
+
+class _Done:
+    """what torch.distributed returns for async_op=True, as far as lkgd_amd.dist uses it"""
+
+    def wait(self):
+        return True
 
 
 def run_ranks(tw: ThreadWorld, fn):
