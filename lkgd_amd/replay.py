@@ -129,8 +129,14 @@ class Arena:
 
     @contextlib.contextmanager
     def allocating(self):
-        """this thread's allocations come from the pool inside (what torch.cuda.use_mem_pool does, per call)"""
-        torch._C._cuda_beginAllocateCurrentThreadToPool(self.device.index, self.pool.id)
+        """this thread's allocations come from the pool inside (what torch.cuda.use_mem_pool does: its three calls, without the
+        generator machinery - a recorded forward enters here once per scratch allocation)"""
+        begin = getattr(torch._C, "_cuda_beginAllocateCurrentThreadToPool", None)
+        if begin is None:                                  # another torch build: the public context manager
+            with torch.cuda.use_mem_pool(self.pool, self.device):
+                yield
+            return
+        begin(self.device.index, self.pool.id)
         try:
             yield
         finally:
